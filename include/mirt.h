@@ -1,0 +1,186 @@
+/* mirt.h — C-ABI of libmirt.so, the MI355X (gfx950) closest-hit + wavefront path-tracing service.
+ *
+ * This is the drop-in boundary for ONE hot path of winmad/Renderer: batched closest-hit
+ * ray/scene intersection over the flattened "KDTree" and the PathTracer per-pixel sample loop.
+ * Every entry point names the reference interface it replaces (file:line under the reference tree).
+ *
+ * Conventions
+ *   - every call returns int: MIRT_OK (0) or a negative MIRT_E_* code; mirt_last_error() gives text.
+ *     The library never calls exit() (the reference does, Shader.cpp:9-12).
+ *   - plain pointers and sizes only; the caller owns every host buffer; the library copies on upload
+ *     and owns its device memory until mirt_destroy().
+ *   - one context per GPU; calls on one context must be serialised by the caller; different
+ *     contexts may be driven from different host threads.
+ *   - ray / hit batches are SoA: `origins` and `directions` are plane-major float[3][n]
+ *     (x-plane, y-plane, z-plane, each n floats) so that wave64 loads are fully coalesced.
+ *   - a miss is t < 0 and tid = -1 (reference convention: Intersection.frag:83, Scene.cpp:443).
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRT_OK            0
+#define MIRT_E_INVALID    -1  /* bad argument / inconsistent scene description            */
+#define MIRT_E_NO_DEVICE  -2  /* no HIP device, or HIP runtime error at context creation   */
+#define MIRT_E_HIP        -3  /* HIP runtime error (text in mirt_last_error)               */
+#define MIRT_E_NO_SCENE   -4  /* intersect / render called before mirt_upload_scene        */
+#define MIRT_E_LIMIT      -5  /* a stated limit was exceeded (tree depth, object count...) */
+
+/* object (material) kinds; they follow the reference's Scene*Object classes */
+#define MIRT_OBJ_DIFFUSE     0  /* SceneDiffuseObject.h:5-21  + DiffuseMaterial.cpp:4-76     */
+#define MIRT_OBJ_GLOSSY      1  /* SceneGlossyObject.h:5-19   + GlossyMaterial.cpp:4-56      */
+#define MIRT_OBJ_REFRACTIVE  2  /* SceneRefractiveObject.h / SceneReflectiveObject.h (ior < 0
+                                   = mirror) + RefractiveMaterial.cpp:4-104                  */
+#define MIRT_OBJ_EMISSIVE    3  /* SceneEmissiveObject.cpp:4-19                              */
+#define MIRT_OBJ_VPM         4  /* SceneVPMObject.cpp:4-233 (homogeneous medium)             */
+
+/* intersection modes */
+#define MIRT_MODE_UNCONDITIONAL 0 /* KDTree::intersect(ray, tid, NULL), KDTree.cpp:335-339    */
+#define MIRT_MODE_LAST_TID      1 /* skip triangle id == aux[i]; Intersection.frag:63-64      */
+#define MIRT_MODE_NO_SELF       2 /* NoSelfIntersectionCondition::legal, .cpp:12-27; aux[i] =
+                                     MIRT_PACK_IDS(contactObject, insideObject)                */
+
+/* aux word for MIRT_MODE_NO_SELF: object ids in [-1, 65533]; -1 = NULL. */
+#define MIRT_PACK_IDS(contact, inside) \
+    ((int32_t)((uint32_t)(((contact) + 1) & 0xFFFF) | ((uint32_t)(((inside) + 1) & 0xFFFF) << 16)))
+#define MIRT_MAX_OBJECTS 65533
+#define MIRT_MAX_TREE_DEPTH 62 /* traversal stack levels available in LDS */
+
+typedef struct MirtContext MirtContext;
+
+/* One scene object = one material (the shipped configs use one Material per object). */
+typedef struct MirtObject {
+    int32_t type;          /* MIRT_OBJ_*                                                     */
+    int32_t has_vn;        /* 1: smooth normals from per-corner vertex normals (tri_vn)      */
+    int32_t volumetric;    /* SceneObject::isVolumetric()                                    */
+    int32_t tri_begin;     /* first global triangle id of this object (Scene.cpp:270)        */
+    int32_t tri_count;
+    float   color[3];      /* diffuse / glossy albedo, emissive radiance, refractive surfColor */
+    float   coeff;         /* glossy exponent (GlossyMaterial.h:20-23)                       */
+    float   ior;           /* refrCoeff; < 0 = mirror; VPM: inrate; 1 otherwise              */
+    float   decay[3];      /* refractive decayColor (RefractiveMaterial.h:15)                */
+    float   sigma_s[3];    /* VPM                                                            */
+    float   sigma_a[3];    /* VPM                                                            */
+    float   g;             /* VPM Henyey-Greenstein g                                        */
+} MirtObject;
+
+/* Flattened scene: what KDTree::serializeForGPU (KDTree.cpp:346-383) + Scene::buildKDTree
+ * (Scene.cpp:248-275) hand to IntersectionGPU::loadKDTreeToShader (IntersectionGPU.cpp:243-255),
+ * with integers kept as integers and the data the CPU hit predicate needs added.
+ *   nodes    : pre-order; left child of inner node i is i+1; node_right[i] = right child or -1
+ *              for a leaf; a leaf owns triangle SLOTS [node_leaf_begin[i], node_leaf_end[i]).
+ *   slots    : triangles in leaf order (each triangle is in exactly one leaf, KDTree.cpp:208-224);
+ *              slot_tid[s] = global triangle id (index into Scene's concatenated triangle list).
+ *   per global triangle id: world-space corner positions, owning object, local triangle id and
+ *              world-space (normal-matrix transformed, not normalised) corner normals.          */
+typedef struct MirtSceneDesc {
+    uint32_t struct_size;           /* sizeof(MirtSceneDesc), for versioning                  */
+    int32_t  n_nodes;
+    const float*   node_min;        /* [n_nodes*3]                                            */
+    const float*   node_max;        /* [n_nodes*3]                                            */
+    const int32_t* node_right;      /* [n_nodes]                                              */
+    const int32_t* node_leaf_begin; /* [n_nodes] (-1 for inner nodes)                         */
+    const int32_t* node_leaf_end;   /* [n_nodes]                                              */
+    int32_t  n_tris;
+    const int32_t* slot_tid;        /* [n_tris]                                               */
+    const float*   tri_pos;         /* [n_tris*9] v0 v1 v2 world positions, by global tid     */
+    const int32_t* tri_obj;         /* [n_tris] object id, by global tid                      */
+    const int32_t* tri_local;       /* [n_tris] triangle id inside its object                 */
+    const float*   tri_vn;          /* [n_tris*9] corner normals by global tid; may be NULL if
+                                       no object has has_vn                                    */
+    int32_t  n_objects;
+    const MirtObject* objects;      /* [n_objects]                                            */
+} MirtSceneDesc;
+
+/* Pinhole camera; fields as Camera.h:13-21 (sightDist is an unsigned int there). */
+typedef struct MirtCamera {
+    int32_t  width, height;
+    uint32_t sight_dist;
+    float    position[3];
+    float    focus[3];
+    float    up[3];
+} MirtCamera;
+
+typedef struct MirtRenderParams {
+    MirtCamera camera;
+    uint32_t spp_begin;      /* first global sample index rendered by this call              */
+    uint32_t spp_count;      /* samples per pixel rendered by this call                      */
+    uint32_t max_depth;      /* MCRenderer::maxDepth (default 20, MCRenderer.h:106)          */
+    uint32_t seed;           /* RNG stream = f(seed, pixel, global sample index, dimension)  */
+    uint32_t spp_per_launch; /* samples per pixel kept in flight per wavefront; 0 = auto     */
+} MirtRenderParams;
+
+typedef struct MirtRenderStats {
+    uint64_t n_samples;      /* camera paths started                                         */
+    uint64_t n_rays;         /* closest-hit queries issued (primary + secondary)             */
+    double   gpu_ms;         /* device time of the whole call, HIP events                    */
+    double   intersect_ms;   /* device time spent in the intersect kernel, HIP events        */
+} MirtRenderStats;
+
+/* --- context ------------------------------------------------------------------------------
+ * replaces IntersectionGPU::init (IntersectionGPU.cpp:16-44: GL context + shader program).   */
+int mirt_create(int device, MirtContext** out);
+int mirt_destroy(MirtContext* ctx);
+/* ctx may be NULL: then the last error of a failed mirt_create on this thread. */
+const char* mirt_last_error(const MirtContext* ctx);
+
+/* --- scene --------------------------------------------------------------------------------
+ * replaces IntersectionGPU::loadKDTreeToShader (IntersectionGPU.cpp:243-255).                */
+int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* scene);
+
+/* --- batched closest hit ------------------------------------------------------------------
+ * replaces IntersectionGPU::query (IntersectionGPU.cpp:216-241) as called from
+ * Scene::fillIntersectObject (Scene.cpp:431-453), and the CPU KDTree::intersect
+ * (KDTree.cpp:295-339) as called from Scene::intersect (Scene.cpp:341-352).
+ * origins, directions: float[3][n] plane-major; aux: int32[n] (ignored, may be NULL, in mode 0);
+ * t_out: float[n]; tid_out: int32[n] global triangle id or -1. Host pointers.                */
+int mirt_intersect(MirtContext* ctx, const float* origins, const float* directions,
+                   const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out);
+/* Same with DEVICE pointers; asynchronous on `stream` (a hipStream_t, NULL = context stream). */
+int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* directions,
+                       const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
+                       void* stream);
+/* Instrumented run (never timed): same results plus the number of node-box tests and
+ * triangle tests summed over the batch (SURVEY.md §8(d) algorithmic-bytes formula). Device ptrs. */
+int mirt_intersect_count_dev(MirtContext* ctx, const float* origins, const float* directions,
+                             const int32_t* aux, size_t n, int mode, float* t_out,
+                             int32_t* tid_out, uint64_t* n_box_tests, uint64_t* n_tri_tests);
+
+/* --- camera rays --------------------------------------------------------------------------
+ * replaces Camera::generateRay (Camera.cpp:4-24) for a batch: ray i = (sample s, pixel p) with
+ * i = (s - spp_begin) * W*H + p. DEVICE pointers float[3][n], n = spp_count*W*H.             */
+int mirt_generate_rays_dev(MirtContext* ctx, const MirtCamera* cam, uint32_t spp_begin,
+                           uint32_t spp_count, uint32_t seed, float* origins, float* directions);
+
+/* --- path tracing -------------------------------------------------------------------------
+ * replaces PathTracer::renderPixels (PathTracer.cpp:4-58) + MCRenderer::samplePath
+ * (MCRenderer.cpp:149-224). rgb_sum: float[W*H*3] (pixel-major r,g,b; row 0 = top), receives
+ * the SUM over the call's samples of the vignetting-compensated path radiance; the caller
+ * divides by the total spp (the reference keeps a running mean, PathTracer.cpp:23,42).
+ * Host pointer version overwrites rgb_sum.                                                   */
+int mirt_render_pt(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
+                   MirtRenderStats* stats /* may be NULL */);
+/* DEVICE pointer version ADDS into rgb_sum (so a multi-call / multi-GPU caller can reduce). */
+int mirt_render_pt_dev(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
+                       MirtRenderStats* stats /* may be NULL */);
+
+/* Secondary-ray capture for the closest-hit benchmark: run the path tracer
+ * for spp_count samples and copy out every secondary ray (origin, direction, packed ids) issued at
+ * bounce depths [depth_lo, depth_hi]. DEVICE pointers; capacity in rays; *n_captured on host.  */
+int mirt_capture_rays_dev(MirtContext* ctx, const MirtRenderParams* params, uint32_t depth_lo,
+                          uint32_t depth_hi, float* origins, float* directions, int32_t* aux,
+                          size_t capacity, size_t* n_captured);
+
+/* device / library facts for logs */
+int mirt_device_info(MirtContext* ctx, char* buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRT_H */

@@ -1,0 +1,61 @@
+/* mirt_host.h — C shims over the C++ host surface (renderer_amd/host/host.h) so that tests and
+ * bench.py can drive the same code a C++ user of Scene / ConfigManager / Renderer drives.
+ * None of these compute on the CPU: scene loading, tree build and flattening are host work in the
+ * reference too (ConfigManager.cpp:166-384, Scene.cpp:248-285, KDTree.cpp:129-246, 346-383);
+ * mirth_upload / mirth_render go to the GPU through include/mirt.h.
+ * Every call returns 0 on success, -1 on failure with text in mirth_last_error().
+ */
+#ifndef MIRT_HOST_H
+#define MIRT_HOST_H
+#include "mirt.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct MirthScene MirthScene;
+
+const char* mirth_last_error(void);
+
+/* Renderer::loadConfig (Renderer.cpp:81-91) without touching the GPU. */
+int mirth_load_config(const char* config_path, MirthScene** out);
+/* A scene from arrays (procedural meshes): world-space vertices, global-index triangles, owning
+ * object per triangle (object triangle ranges must be contiguous and ordered), optional corner
+ * normals [T*9]; builds the tree like Scene::buildKDTree. */
+int mirth_scene_from_arrays(int32_t n_verts, const float* verts, int32_t n_tris, const uint32_t* tris,
+                            const int32_t* tri_obj, const float* tri_vn, int32_t n_objects,
+                            const MirtObject* objects, MirthScene** out);
+void mirth_free(MirthScene* s);
+
+/* sizes: n_verts, n_tris, n_objects, n_nodes, tree depth */
+int mirth_counts(const MirthScene* s, int32_t out[5]);
+/* raw (pre-tree) scene, caller-allocated arrays sized from mirth_counts; any pointer may be NULL */
+int mirth_get_raw(const MirthScene* s, float* verts, uint32_t* tris, int32_t* tri_obj,
+                  int32_t* tri_local, float* tri_vn, MirtObject* objects);
+/* flattened tree (pre-order) */
+int mirth_get_tree(const MirthScene* s, float* node_min, float* node_max, int32_t* node_right,
+                   int32_t* leaf_begin, int32_t* leaf_end, int32_t* slot_tid);
+int mirth_get_camera(const MirthScene* s, MirtCamera* cam);
+/* integrator settings read from the config: max_depth, spp, seed */
+int mirth_get_render_cfg(const MirthScene* s, uint32_t out[3]);
+/* the descriptor the device upload takes; pointers live as long as the scene */
+int mirth_describe(const MirthScene* s, MirtSceneDesc* desc);
+
+/* Scene::buildKDTree's upload step: IntersectionHIP::init + loadKDTreeToDevice; *ctx_out receives
+ * the service's context so callers can use the mirt_* entry points on the same scene. */
+int mirth_upload(MirthScene* s, MirtContext** ctx_out);
+/* Renderer::render (Renderer.cpp:46-50) through PathTracerHIP::renderPixels: mean image
+ * rgb[W*H*3]; spp/seed 0 = take the config's. */
+int mirth_render(MirthScene* s, uint32_t spp, uint32_t seed, float* rgb_mean, MirtRenderStats* stats);
+/* Scene::fillIntersectObject (Scene.cpp:431-453) on AoS rays: o[n*3], d[n*3], contact/inside
+ * object ids (-1 = NULL) -> dist[n], global tid[n] (-1 = miss), objID[n], local triangle id[n] */
+int mirth_fill_intersect(MirthScene* s, size_t n, const float* o, const float* d, const int32_t* contact,
+                         const int32_t* inside, float* dist, int32_t* tid, int32_t* obj, int32_t* local);
+void mirth_shutdown(void);
+
+int mirth_save_pfm(const char* path, const float* rgb, int32_t w, int32_t h);
+int mirth_load_pfm(const char* path, float* rgb, int32_t capacity_pixels, int32_t wh[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1104 @@
+// oracle.cpp — CPU restatement of the reference hot path. TEST INFRASTRUCTURE ONLY (see oracle.h).
+// PARITY UNPINNED (see oracle.h): no reference fixtures exist and the reference cannot be built here.
+//
+// Written in the reference's own shape so it can be read beside the files it cites:
+//   tree build      KDTree.cpp:129-246      box test     KDTree.cpp:34-52
+//   triangle test   KDTree.cpp:267-293      traversal    KDTree.cpp:295-339
+//   flatten         KDTree.cpp:346-383      predicate    NoSelfIntersectionCondition.cpp:12-27
+//   normals/frames  SimpleShape.cpp:300-339, LocalFrame.h:14-28
+//   materials       DiffuseMaterial.cpp:4-76, GlossyMaterial.cpp:4-56, RefractiveMaterial.cpp:4-104,
+//                   SceneEmissiveObject.cpp:4-19
+//   path sampling   MCRenderer.cpp:149-224  accumulation PathTracer.cpp:23-42
+//   camera          Camera.cpp:4-48,60-78,92-97
+// The one deliberate difference: the reference's global MT19937 (RandGenerator.cpp:9, racy under
+// OpenMP) is replaced by the counter-based stream the product uses (DESIGN.md "RNG"), consumed in
+// the same order the reference consumes its generator.
+#include "oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <unordered_set>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+// ---- nvVector.h semantics --------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(float a, float b, float c) : x(a), y(b), z(c) {}
+    float& operator[](int i) { return (&x)[i]; }
+    const float& operator[](int i) const { return (&x)[i]; }
+};
+inline V3 operator+(const V3& a, const V3& b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(const V3& a, const V3& b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(const V3& a) { return V3(-a.x, -a.y, -a.z); }
+inline V3 operator*(const V3& a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(float s, const V3& a) { return V3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(const V3& a, const V3& b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+// nvVector.h:376-380: dividing by zero leaves the vector unchanged
+inline V3 operator/(const V3& a, float d) {
+    if (d == 0) return a;
+    return V3(a.x / d, a.y / d, a.z / d);
+}
+// nvVector.h:501-507: r = 0; r += x*x; r += y*y; r += z*z
+inline float dot(const V3& a, const V3& b) {
+    float r = 0;
+    r += a.x * b.x;
+    r += a.y * b.y;
+    r += a.z * b.z;
+    return r;
+}
+// nvVector.h:490-498
+inline V3 cross(const V3& l, const V3& r) {
+    return V3(l.y * r.z - l.z * r.y, l.z * r.x - l.x * r.z, l.x * r.y - l.y * r.x);
+}
+inline float length(const V3& a) { return std::sqrt(dot(a, a)); }
+// nvVector.h:522-526
+inline void normalize(V3& a) {
+    float r = length(a);
+    if (r > 0) a = a / r;
+}
+
+const double REF_PI = 3.14159265358979;  // macros.h:9 (a double literal)
+const float COS_TERM_MIN = 1e-6f;         // macros.h:7
+
+// ---- counter RNG (DESIGN.md "RNG") ------------------------------------------------------------
+inline uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+struct Stream {
+    uint32_t key, ctr;
+    Stream(uint32_t seed, uint32_t pixel, uint32_t sample) {
+        uint32_t h1 = lowbias32(sample + 0x9E3779B9U * (seed + 1U));
+        key = lowbias32(pixel ^ h1);
+        ctr = 0;
+    }
+    uint32_t bits() { return lowbias32(key + 0x9E3779B9U * (ctr++)); }
+    // RandGenerator.cpp:21-25 keeps 24 bits: value in [0,1) on a 2^-24 grid
+    float genFloat() { return float(bits() >> 8) / float(1 << 24); }
+};
+
+// ---- tree (KDTree.h:61-72) ----------------------------------------------------------------------
+struct Node {
+    Node* left = nullptr;
+    Node* right = nullptr;
+    std::vector<unsigned> triangleIndices;
+    V3 minCoord, maxCoord;
+};
+
+struct Tri {
+    unsigned v[3];
+};
+
+struct KRay {
+    V3 origin, direction;
+};
+
+}  // namespace
+
+struct OrcScene {
+    std::vector<V3> verts;
+    std::vector<Tri> tris;
+    std::vector<int32_t> triObj, triLocal;
+    std::vector<V3> triVn;  // 3 per triangle, may be empty
+    std::vector<OrcObject> objects;
+    Node* root = nullptr;
+    // flattened view (pre-order) used by the ordered-traversal restatement
+    std::vector<V3> fmin, fmax;
+    std::vector<int32_t> fright, fbegin, fend, slotTid;
+    int depth = 0;
+};
+
+namespace {
+
+void destroyNode(Node* n) {
+    if (!n) return;
+    destroyNode(n->left);
+    destroyNode(n->right);
+    delete n;
+}
+
+// KDTree.cpp:129-228
+void splitBest(OrcScene& S, Node* node, int depth, int& maxDepthSeen) {
+    if (depth > maxDepthSeen) maxDepthSeen = depth;
+    float bestRatio = 10;
+    unsigned bestDim = 0;
+    float bestSplitValue = 0;
+    for (unsigned dim = 0; dim < 3; dim++) {
+        node->left = node->right = nullptr;
+        if (node->triangleIndices.size() == 0) return;
+        node->minCoord = node->maxCoord = S.verts[S.tris[node->triangleIndices[0]].v[0]];
+        std::unordered_set<unsigned> nodeVertexIndices;
+        for (size_t i = 0; i < node->triangleIndices.size(); i++) {
+            for (unsigned k = 0; k < 3; k++) {
+                unsigned vi = S.tris[node->triangleIndices[i]].v[k];
+                const V3& p = S.verts[vi];
+                for (int c = 0; c < 3; c++) {
+                    node->minCoord[c] = p[c] < node->minCoord[c] ? p[c] : node->minCoord[c];
+                    node->maxCoord[c] = p[c] > node->maxCoord[c] ? p[c] : node->maxCoord[c];
+                }
+                nodeVertexIndices.insert(vi);
+            }
+        }
+        // maxDepth = (unsigned)-1 and maxLeafTriangleNum = 1 (KDTree.cpp:22-27)
+        if (node->triangleIndices.size() <= 1) return;
+
+        std::vector<float> coordList;
+        coordList.reserve(nodeVertexIndices.size());
+        for (unsigned vi : nodeVertexIndices) coordList.push_back(S.verts[vi][dim]);
+        std::nth_element(coordList.begin(), coordList.begin() + (coordList.size() >> 1),
+                         coordList.end());
+        float splitValue = coordList[coordList.size() >> 1];
+
+        unsigned leftCount = 0;
+        for (size_t i = 0; i < node->triangleIndices.size(); i++) {
+            unsigned mask = 0;
+            for (unsigned k = 0; k < 3; k++) {
+                const V3& p = S.verts[S.tris[node->triangleIndices[i]].v[k]];
+                mask += (p[dim] <= splitValue) << k;
+            }
+            if (mask != 0) leftCount++;
+        }
+        float ratio = leftCount / float(node->triangleIndices.size());
+        // KDTree.cpp:191: float - double literal, std::abs(double)
+        if (std::abs(ratio - 0.5) < std::abs(bestRatio - 0.5)) {
+            bestRatio = ratio;
+            bestDim = dim;
+            bestSplitValue = splitValue;
+        }
+    }
+    if (bestRatio == 0 || bestRatio == 1) {
+        node->left = node->right = nullptr;
+        return;
+    }
+    node->left = new Node;
+    node->right = new Node;
+    for (size_t i = 0; i < node->triangleIndices.size(); i++) {
+        unsigned mask = 0;
+        for (unsigned k = 0; k < 3; k++) {
+            const V3& p = S.verts[S.tris[node->triangleIndices[i]].v[k]];
+            mask += (p[bestDim] <= bestSplitValue) << k;
+        }
+        if (mask == 0)
+            node->right->triangleIndices.push_back(node->triangleIndices[i]);
+        else
+            node->left->triangleIndices.push_back(node->triangleIndices[i]);
+    }
+    splitBest(S, node->left, depth + 1, maxDepthSeen);
+    splitBest(S, node->right, depth + 1, maxDepthSeen);
+}
+
+// KDTree.cpp:34-52
+float boxIntersect(const V3& minC, const V3& maxC, const KRay& ray) {
+    V3 intPoint;
+    float minDist = -1;
+    for (unsigned i = 0; i < 6; i++) {
+        if (ray.direction[i % 3] == 0) continue;
+        float plane = i < 3 ? minC[i] : maxC[i - 3];
+        float dist = (plane - ray.origin[i % 3]) / ray.direction[i % 3];
+        intPoint = ray.origin + dist * ray.direction;
+        bool inter = dist >= 0;
+        inter &= minC[(i + 1) % 3] <= intPoint[(i + 1) % 3];
+        inter &= maxC[(i + 1) % 3] >= intPoint[(i + 1) % 3];
+        inter &= minC[(i + 2) % 3] <= intPoint[(i + 2) % 3];
+        inter &= maxC[(i + 2) % 3] >= intPoint[(i + 2) % 3];
+        minDist = (inter && (dist < minDist || minDist < 0)) ? dist : minDist;
+    }
+    return minDist;
+}
+
+// SimpleShape.cpp:300-339 (world positions already transformed; vns already multiplied by the
+// normal matrix on the host, SimpleShape.cpp:310,322)
+V3 worldNormal(const OrcScene& S, unsigned tid, const V3& position) {
+    V3 vps[3];
+    for (int i = 0; i < 3; i++) vps[i] = S.verts[S.tris[tid].v[i]];
+    V3 b1 = vps[1] - vps[0];
+    V3 b2 = vps[2] - vps[0];
+    V3 faceNormal = cross(b1, b2);
+    normalize(faceNormal);
+    const OrcObject& obj = S.objects[S.triObj[tid]];
+    if (!obj.has_vn || S.triVn.empty()) return faceNormal;
+    const V3* vns = &S.triVn[3 * (size_t)tid];
+    V3 v = position - vps[0];
+    float d12 = dot(b1, b2);
+    float l1 = length(b1);
+    float l2 = length(b2);
+    float u2 = (dot(v, b1) * d12 - dot(v, b2) * l1 * l1) / (d12 * d12 - l1 * l1 * l2 * l2);
+    float u1 = (dot(v, b1) - u2 * d12) / (l1 * l1);
+    V3 normal = (1 - u1 - u2) * vns[0] + u1 * vns[1] + u2 * vns[2];
+    normalize(normal);
+    return normal;
+}
+
+// NoSelfIntersectionCondition.cpp:12-27
+struct Condition {
+    int mode = 0;  // 0 none, 1 last_tid, 2 NoSelfIntersection
+    int lastTid = -1;
+    int contact = -1, inside = -1;
+    bool legal(const OrcScene& S, const KRay& ray, unsigned tid, float dist) const {
+        if (mode == 0) return true;
+        if (mode == 1) return (int)tid != lastTid;
+        int hitObj = S.triObj[tid];
+        float d = dot(ray.direction, worldNormal(S, tid, ray.origin + ray.direction * dist));
+        bool in = d <= 0;
+        bool out = d >= 0;
+        if (inside == contact) return !(in && contact == hitObj);
+        return !(out && inside != hitObj);
+    }
+};
+
+// KDTree.cpp:267-293
+float triIntersect(const OrcScene& S, const KRay& ray, unsigned tid, const Condition* cond) {
+    V3 vs[3], lines[3], r2v, n;
+    for (unsigned i = 0; i < 3; i++) vs[i] = S.verts[S.tris[tid].v[i]];
+    unsigned mask_pos = 0, mask_neg = 0;
+    for (unsigned i = 0; i < 3; i++) {
+        lines[i] = vs[(i + 1) % 3] - vs[i];
+        r2v = vs[i] - ray.origin;
+        n = cross(lines[i], r2v);
+        mask_pos += (dot(ray.direction, n) >= 0) << i;
+        mask_neg += (dot(ray.direction, n) <= 0) << i;
+    }
+    n = cross(lines[0], lines[1]);
+    normalize(n);
+    float orthoDist = dot(n, r2v);
+    float d = dot(n, ray.direction);
+    if (d == 0 || orthoDist / d < 0 || (mask_pos != 7 && mask_neg != 7)) return -1;
+    float dist = orthoDist / d;
+    if (cond && !cond->legal(S, ray, tid, dist)) return -1;
+    return dist;
+}
+
+struct Counters {
+    uint64_t box = 0, tri = 0;
+};
+
+// KDTree.cpp:295-333
+float nodeIntersect(const OrcScene& S, const KRay& ray, const Node* node, unsigned& triangleID,
+                    const Condition* cond, Counters* cnt) {
+    if (cnt) cnt->box++;
+    if (boxIntersect(node->minCoord, node->maxCoord, ray) < 0) return -1;
+    if (node->left == nullptr && node->right == nullptr) {
+        float minDist = -1;
+        for (size_t ti = 0; ti < node->triangleIndices.size(); ti++) {
+            if (cnt) cnt->tri++;
+            float dist = triIntersect(S, ray, node->triangleIndices[ti], cond);
+            if (dist >= 0 && (dist < minDist || minDist < 0)) {
+                minDist = dist;
+                triangleID = node->triangleIndices[ti];
+            }
+        }
+        return minDist;
+    }
+    float ld, rd;
+    unsigned ltid = 0, rtid = 0;
+    ld = nodeIntersect(S, ray, node->left, ltid, cond, cnt);
+    rd = nodeIntersect(S, ray, node->right, rtid, cond, cnt);
+    if (ld >= 0 && rd >= 0) {
+        triangleID = ld < rd ? ltid : rtid;
+        return ld < rd ? ld : rd;
+    } else if (rd < 0) {
+        triangleID = ltid;
+        return ld;
+    } else if (ld < 0) {
+        triangleID = rtid;
+        return rd;
+    }
+    return -1;
+}
+
+// KDTree.cpp:346-377 (integers kept as integers; triangles referenced by slot -> global id)
+void flattenNode(OrcScene& S, const Node* node) {
+    S.fmin.push_back(node->minCoord);
+    S.fmax.push_back(node->maxCoord);
+    if (node->left && node->right) {
+        S.fright.push_back(-1);
+        S.fbegin.push_back(-1);
+        S.fend.push_back(-1);
+        size_t me = S.fright.size() - 1;
+        flattenNode(S, node->left);
+        S.fright[me] = (int32_t)S.fright.size();
+        flattenNode(S, node->right);
+    } else {
+        int32_t si = (int32_t)S.slotTid.size();
+        for (unsigned t : node->triangleIndices) S.slotTid.push_back((int32_t)t);
+        S.fright.push_back(-1);
+        S.fbegin.push_back(si);
+        S.fend.push_back((int32_t)S.slotTid.size());
+    }
+}
+
+Condition makeCond(int mode, int32_t aux) {
+    Condition c;
+    c.mode = mode;
+    if (mode == 1) c.lastTid = aux;
+    if (mode == 2) {
+        c.contact = (int)((uint32_t)aux & 0xFFFFu) - 1;
+        c.inside = (int)(((uint32_t)aux >> 16) & 0xFFFFu) - 1;
+    }
+    return c;
+}
+
+// ---- the product's traversal order, restated for visit counts (DESIGN.md "intersect kernel") ----
+struct BoxRes {
+    bool hit;
+    float lb;
+};
+BoxRes boxOrdered(const V3& minC, const V3& maxC, const KRay& ray) {
+    BoxRes r;
+    r.hit = boxIntersect(minC, maxC, ray) >= 0;
+    float lb = 0;
+    for (int a = 0; a < 3; a++) {
+        if (ray.direction[a] == 0) continue;
+        float t0 = (minC[a] - ray.origin[a]) / ray.direction[a];
+        float t1 = (maxC[a] - ray.origin[a]) / ray.direction[a];
+        float nr = t0 < t1 ? t0 : t1;
+        lb = nr > lb ? nr : lb;
+    }
+    r.lb = lb;
+    return r;
+}
+inline bool pruned(float lb, bool have, float best) { return have && lb > best * 1.0001f + 1e-5f; }
+
+float orderedIntersect(const OrcScene& S, const KRay& ray, const Condition& cond, int& slotOut,
+                       Counters& cnt) {
+    float best = -1;
+    int bestSlot = -1;
+    struct E {
+        int node;
+        float lb;
+    };
+    std::vector<E> stack;
+    cnt.box++;
+    if (!boxOrdered(S.fmin[0], S.fmax[0], ray).hit) {
+        slotOut = -1;
+        return -1;
+    }
+    int cur = 0;
+    for (;;) {
+        bool pop = false;
+        if (S.fright[cur] < 0) {
+            int lb = S.fbegin[cur], le = S.fend[cur];
+            for (int s = lb; s < le; s++) {
+                cnt.tri++;
+                unsigned tid = (unsigned)S.slotTid[s];
+                float t = triIntersect(S, ray, tid, nullptr);
+                if (!(t >= 0)) continue;
+                bool wins = bestSlot < 0 || t < best || (t == best && bestSlot < lb);
+                if (wins && cond.legal(S, ray, tid, t)) {
+                    best = t;
+                    bestSlot = s;
+                }
+            }
+            pop = true;
+        } else {
+            int L = cur + 1, R = S.fright[cur];
+            cnt.box += 2;
+            BoxRes bl = boxOrdered(S.fmin[L], S.fmax[L], ray);
+            BoxRes br = boxOrdered(S.fmin[R], S.fmax[R], ray);
+            bool hl = bl.hit && !pruned(bl.lb, bestSlot >= 0, best);
+            bool hr = br.hit && !pruned(br.lb, bestSlot >= 0, best);
+            if (hl && hr) {
+                if (bl.lb <= br.lb) {
+                    stack.push_back({R, br.lb});
+                    cur = L;
+                } else {
+                    stack.push_back({L, bl.lb});
+                    cur = R;
+                }
+            } else if (hl) {
+                cur = L;
+            } else if (hr) {
+                cur = R;
+            } else {
+                pop = true;
+            }
+        }
+        if (pop) {
+            bool found = false;
+            while (!stack.empty()) {
+                E e = stack.back();
+                stack.pop_back();
+                if (pruned(e.lb, bestSlot >= 0, best)) continue;
+                cur = e.node;
+                found = true;
+                break;
+            }
+            if (!found) break;
+        }
+    }
+    slotOut = bestSlot;
+    return bestSlot >= 0 ? best : -1;
+}
+
+// ---- path tracing ---------------------------------------------------------------------------------
+const int CAMERA_OBJ = -2;  // Camera is a SceneObject used as contactObject (Camera.cpp:25)
+
+// Ray.h:8-61 (fields the PathTracer path reads)
+struct PRay {
+    V3 origin, direction, color;
+    float directionProb, originProb;
+    int insideObject, contactObject, intersectObject;  // object ids, -1 = NULL
+    unsigned contactObjectTriangleID, intersectObjectTriangleID;
+    float intersectDist;
+    PRay() {  // Ray.h:37-51
+        insideObject = intersectObject = contactObject = -1;
+        color = V3(1, 1, 1);
+        directionProb = 1;
+        originProb = 1;
+        contactObjectTriangleID = intersectObjectTriangleID = 0;
+        intersectDist = -1;
+    }
+};
+
+// LocalFrame.h:8-34
+struct LocalFrame {
+    V3 s, t, n;
+    void buildFromNormal(const V3& normal) {
+        n = normal;
+        V3 tmpT = (std::abs(n.z) > 0.99f) ? V3(1, 0, 0) : V3(0, 0, 1);
+        s = cross(n, tmpT);
+        normalize(s);
+        t = cross(s, n);
+        normalize(t);
+    }
+    V3 toWorld(const V3& a) const { return s * a.x + n * a.y + t * a.z; }
+};
+
+struct Tracer {
+    const OrcScene& S;
+    const OrcCamera& cam;
+    unsigned maxDepth;
+    uint64_t nRays = 0;
+    V3 camPos, camFront;
+    Tracer(const OrcScene& s, const OrcCamera& c, unsigned md) : S(s), cam(c), maxDepth(md) {
+        camPos = V3(c.position[0], c.position[1], c.position[2]);
+        camFront = V3(c.focus[0], c.focus[1], c.focus[2]) - camPos;
+        normalize(camFront);
+    }
+
+    unsigned globalTid(int obj, unsigned local) const { return S.objects[obj].tri_begin + local; }
+
+    // SceneObject::getWorldNormal, flat=false, no bump texture (SceneObject.cpp:250-254)
+    V3 objNormal(int obj, unsigned localTri, const V3& pos) const {
+        return worldNormal(S, globalTid(obj, localTri), pos);
+    }
+
+    // Ray.cpp:5-12, Camera.cpp:92-97
+    V3 contactNormal(const PRay& r) const {
+        if (r.contactObject == CAMERA_OBJ) {
+            V3 front = V3(cam.focus[0], cam.focus[1], cam.focus[2]) - r.origin;
+            normalize(front);
+            return front;
+        }
+        if (r.contactObject >= 0) return objNormal(r.contactObject, r.contactObjectTriangleID, r.origin);
+        return V3(0, 0, 0);
+    }
+    bool hasCosineTerm(int obj) const {
+        if (obj == CAMERA_OBJ) return true;
+        return S.objects[obj].type != ORC_VPM;  // SceneVPMObject.h: hasCosineTerm() false
+    }
+    // Ray.cpp:71-78
+    float cosineTerm(const PRay& r) const {
+        float d = 1.f;
+        if (r.contactObject != -1 && hasCosineTerm(r.contactObject) && length(r.direction) > 0.5)
+            d = std::abs(dot(contactNormal(r), r.direction));
+        d = d > COS_TERM_MIN ? d : COS_TERM_MIN;
+        return d;
+    }
+    // Ray.cpp:66-69, SceneObject.cpp:354-364, RefractiveMaterial.h:15
+    V3 radianceDecay(const PRay& r, float dist) const {
+        if (r.insideObject < 0) return V3(1, 1, 1);
+        const OrcObject& o = S.objects[r.insideObject];
+        if (o.type == ORC_REFRACTIVE)
+            return V3(powf(o.decay[0], dist), powf(o.decay[1], dist), powf(o.decay[2], dist));
+        return V3(1, 1, 1);
+    }
+    bool emissive(int obj) const { return obj >= 0 && S.objects[obj].type == ORC_EMISSIVE; }
+
+    // RandGenerator.cpp:152-168 (disk.x drawn first)
+    static V3 hemiCos(float expTerm, float dx, float dy) {
+        float u1 = 2.f * REF_PI * dx;
+        float u2 = std::pow(dy, 1.f / (expTerm + 1.f));
+        float u3 = std::sqrt(1.f - u2 * u2);
+        V3 res(std::cos(u1) * u3, u2, std::sin(u1) * u3);
+        normalize(res);
+        return res;
+    }
+    // CosineSphericalSampler.h:23-34
+    static float cosPdf(const LocalFrame& lf, const V3& dir, float coeff) {
+        float c = dot(lf.n, dir);
+        float cosTheta = c > 0.f ? c : 0.f;
+        float res = (powf(cosTheta, coeff) * (coeff + 1.f) / (2.f * REF_PI));
+        return res;
+    }
+
+    // Scene::findInsideObject (Scene.cpp:354-390): only volumetric objects count. The homogeneous
+    // medium (config C5) is not restated yet, so there are none.
+    int findInsideObject(const PRay&, int) const { return -1; }
+
+    // DiffuseMaterial.cpp:4-76
+    PRay scatterDiffuse(int object, const PRay& in, Stream& rng) const {
+        PRay out;
+        out.origin = in.origin + in.direction * in.intersectDist;
+        LocalFrame lf;
+        lf.buildFromNormal(objNormal(in.intersectObject, in.intersectObjectTriangleID, out.origin));
+        const OrcObject& o = S.objects[object];
+        V3 color(o.color[0], o.color[1], o.color[2]);
+        V3 normal = lf.n;
+        out.insideObject = in.insideObject;
+        out.intersectObject = -1;
+        out.contactObject = object;
+        out.contactObjectTriangleID = in.intersectObjectTriangleID;
+        if (dot(in.direction, normal) > 0) {  // hit from behind: pass straight through
+            out.direction = in.direction;
+            out.directionProb = 1;
+            out.color = V3(1, 1, 1);
+            return out;
+        }
+        float dx = rng.genFloat(), dy = rng.genFloat();
+        out.direction = lf.toWorld(hemiCos(1.f, dx, dy));
+        float p = std::max(color.x, std::max(color.y, color.z));
+        if (rng.genFloat() < p) {
+            // DiffuseBSDF.h:18-24
+            if (dot(lf.n, in.direction) <= 0 && dot(lf.n, out.direction) >= 0)
+                out.color = color / float(REF_PI);
+            else
+                out.color = V3(0, 0, 0);
+            out.directionProb = p * cosPdf(lf, out.direction, 1.f);
+        } else {
+            out.direction = V3(0, 0, 0);
+            out.color = V3(0, 0, 0);
+            out.directionProb = 1 - p;
+        }
+        return out;
+    }
+
+    // GlossyMaterial.cpp:4-56, GlossyBSDF.h:24-33
+    PRay scatterGlossy(int object, const PRay& in, Stream& rng) const {
+        PRay out;
+        V3 position = in.origin + in.direction * in.intersectDist;
+        LocalFrame lf;
+        lf.buildFromNormal(objNormal(in.intersectObject, in.intersectObjectTriangleID, position));
+        V3 normal = lf.n;
+        const OrcObject& o = S.objects[object];
+        V3 color(o.color[0], o.color[1], o.color[2]);
+        float coeff = o.coeff;
+        out.insideObject = in.insideObject;
+        out.origin = position;
+        out.contactObject = object;
+        out.contactObjectTriangleID = in.intersectObjectTriangleID;
+        LocalFrame out_lf;
+        V3 reflDir = -dot(normal, in.direction) * normal * 2 + in.direction;
+        out_lf.buildFromNormal(reflDir);
+        float dx = rng.genFloat(), dy = rng.genFloat();
+        out.direction = out_lf.toWorld(hemiCos(coeff, dx, dy));
+        out.color = V3(0, 0, 0);
+        if (dot(lf.n, in.direction) <= 0 && dot(lf.n, out.direction) >= 0) {
+            V3 r2 = -dot(lf.n, in.direction) * lf.n * 2 + in.direction;
+            if (dot(r2, out.direction) > 0) out.color = color * powf(dot(r2, out.direction), coeff);
+        }
+        out.directionProb = cosPdf(out_lf, out.direction, coeff);
+        float p = std::max(color.x, std::max(color.y, color.z));
+        if (length(out.color) == 0) {
+            out.direction = V3(0, 0, 0);
+            out.color = V3(0, 0, 0);
+            out.directionProb = 1;
+            return out;
+        }
+        if (rng.genFloat() < p) {
+            out.directionProb *= p;
+        } else {
+            out.direction = V3(0, 0, 0);
+            out.color = V3(0, 0, 0);
+            out.directionProb = 1 - p;
+        }
+        return out;
+    }
+
+    // smallFuncs.h:11-24 applied to a direction (w = 0)
+    static V3 rotate(const V3& axis, float angle, const V3& v) {
+        float c = std::cos(angle), s = std::sin(angle);
+        float _c = 1 - c;
+        float x = axis.x, y = axis.y, z = axis.z;
+        float m00 = c + _c * x * x, m01 = _c * x * y - s * z, m02 = _c * x * z + s * y;
+        float m10 = _c * x * y + s * z, m11 = c + _c * y * y, m12 = _c * y * z - s * x;
+        float m20 = _c * x * z - s * y, m21 = _c * y * z + s * x, m22 = c + _c * z * z;
+        // nvMatrix.h:415-424 with src.w = 0
+        return V3(v.x * m00 + v.y * m01 + v.z * m02 + 0.f * 0.f,
+                  v.x * m10 + v.y * m11 + v.z * m12 + 0.f * 0.f,
+                  v.x * m20 + v.y * m21 + v.z * m22 + 0.f * 0.f);
+    }
+    static float clampf(float v, float lo, float hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+    // RefractiveMaterial.cpp:4-104
+    PRay scatterRefractive(int object, const PRay& in, Stream& rng) const {
+        PRay out;
+        V3 position = in.origin + in.direction * in.intersectDist;
+        const OrcObject& o = S.objects[object];
+        LocalFrame lf;
+        lf.buildFromNormal(objNormal(in.intersectObject, in.intersectObjectTriangleID, position));
+        V3 normal = lf.n;
+        out.color = V3(o.color[0], o.color[1], o.color[2]);
+        out.origin = position;
+        out.direction = in.direction;
+        V3 reflDir = -dot(normal, in.direction) * normal * 2 + in.direction;
+        out.contactObject = object;
+        out.contactObjectTriangleID = in.intersectObjectTriangleID;
+        if (o.ior < 0) {  // mirror
+            out.direction = reflDir;
+            out.insideObject = in.insideObject;
+            out.directionProb = 1;
+            out.color = out.color / cosineTerm(out);
+            return out;
+        }
+        if (in.intersectObject != object && in.insideObject == object)
+            return scatter(in.intersectObject, in, rng);
+
+        float theta = std::acos(clampf(dot(in.direction, normal), -1, 1));
+        int currentInside = in.insideObject;
+        int outSide = object;
+        if (in.insideObject == object) outSide = findInsideObject(out, object);
+        float current_n = currentInside >= 0 ? refrCoeff(currentInside) : 1;
+        float next_n = outSide >= 0 ? refrCoeff(outSide) : 1;
+        out.intersectObject = -1;
+        out.directionProb = 1;
+        float sin_phi = current_n / next_n * std::sin(theta);
+        if (sin_phi >= 1) {
+            out.direction = reflDir;
+            out.insideObject = in.insideObject;
+            out.directionProb = 1;
+            out.color = out.color / cosineTerm(out);
+        } else {
+            float phi = std::asin(sin_phi);
+            if (theta > REF_PI / 2) phi = REF_PI - phi;
+            V3 axis = cross(normal, in.direction);
+            normalize(axis);
+            out.direction = rotate(axis, phi, normal);
+            normalize(out.direction);
+            float cos_theta = std::abs(std::cos(theta));
+            float cos_phi = std::abs(std::cos(phi));
+            float esr = powf(std::abs(current_n * cos_theta - next_n * cos_phi) /
+                                 (current_n * cos_theta + next_n * cos_phi), 2);
+            float epr = powf(std::abs(next_n * cos_theta - current_n * cos_phi) /
+                                 (next_n * cos_theta + current_n * cos_phi), 2);
+            float er = (esr + epr) / 2;
+            float p = clampf(er, 0.f, 1.f);
+            if (rng.genFloat() < p) {
+                out.direction = reflDir;
+                out.color = out.color * (er / cosineTerm(out));
+                out.directionProb = p;
+                out.insideObject = in.insideObject;
+            } else {
+                out.color = out.color * ((1 - er) / cosineTerm(out));
+                out.directionProb = 1 - p;
+                out.insideObject = outSide;
+            }
+        }
+        normalize(out.direction);
+        return out;
+    }
+    // SceneObject.h:58, SceneRefractiveObject.h:22 (mirrors keep the SceneObject default 1)
+    float refrCoeff(int obj) const {
+        const OrcObject& o = S.objects[obj];
+        if (o.type == ORC_REFRACTIVE && o.ior >= 0) return o.ior;
+        if (o.type == ORC_VPM) return o.ior;
+        return 1;
+    }
+
+    // SceneEmissiveObject.cpp:4-19
+    PRay scatterEmissive(int object, const PRay& in) const {
+        PRay out;
+        V3 position = in.origin + in.direction * in.intersectDist;
+        out.intersectObject = -1;
+        out.insideObject = -1;
+        out.contactObject = object;
+        out.contactObjectTriangleID = in.intersectObjectTriangleID;
+        out.origin = position;
+        out.direction = V3(0, 0, 0);
+        const OrcObject& o = S.objects[object];
+        out.color = dot(in.direction, contactNormal(out)) <= 0 ? V3(o.color[0], o.color[1], o.color[2])
+                                                               : V3(0, 0, 0);
+        out.directionProb = 1;
+        return out;
+    }
+
+    // SceneObject.cpp:366-373 (one material per object; the rand() it burns feeds nothing)
+    PRay scatter(int object, const PRay& in, Stream& rng) const {
+        switch (S.objects[object].type) {
+            case ORC_DIFFUSE: return scatterDiffuse(object, in, rng);
+            case ORC_GLOSSY: return scatterGlossy(object, in, rng);
+            case ORC_REFRACTIVE: return scatterRefractive(object, in, rng);
+            case ORC_EMISSIVE: return scatterEmissive(object, in);
+            default: {
+                PRay dead;  // unsupported kind: terminate the path with zero weight
+                dead.direction = V3(0, 0, 0);
+                dead.color = V3(0, 0, 0);
+                dead.origin = in.origin;
+                return dead;
+            }
+        }
+    }
+
+    // Scene::intersect (Scene.cpp:341-352)
+    float sceneIntersect(const PRay& r, const Condition* cond, int& objID, unsigned& localTri) {
+        KRay k;
+        k.origin = r.origin;
+        k.direction = r.direction;
+        unsigned tid = 0;
+        nRays++;
+        float dist = nodeIntersect(S, k, S.root, tid, cond, nullptr);
+        if (dist >= 0) {
+            objID = S.triObj[tid];
+            localTri = (unsigned)S.triLocal[tid];
+        }
+        return dist;
+    }
+
+    // Camera.cpp:4-48
+    PRay generateRay(unsigned pixelID, Stream& rng) {
+        V3 front = V3(cam.focus[0], cam.focus[1], cam.focus[2]) - camPos;
+        normalize(front);
+        V3 up(cam.up[0], cam.up[1], cam.up[2]);
+        V3 right = cross(front, up);
+        normalize(right);
+        V3 orthoUp = cross(right, front);
+        PRay ray;
+        int x = pixelID % cam.width;
+        int y = pixelID / cam.width;
+        float u = rng.genFloat();
+        float v = rng.genFloat();
+        ray.direction = front * float(cam.sight_dist) + right * float(x + u - (cam.width / 2.0)) +
+                        orthoUp * float((cam.height / 2.0) - v - y);
+        normalize(ray.direction);
+        ray.color = V3(1, 1, 1);
+        ray.origin = camPos;
+        ray.contactObject = CAMERA_OBJ;
+        int oid = -1;
+        unsigned lt = 0;
+        ray.intersectDist = sceneIntersect(ray, nullptr, oid, lt);
+        ray.intersectObjectTriangleID = lt;
+        ray.intersectObject = ray.intersectDist >= 0 ? oid : -1;
+        ray.insideObject = findInsideObject(ray, -1);
+        ray.directionProb = 1.f;
+        return ray;
+    }
+
+    // Camera.cpp:60-78
+    V3 eliminateVignetting(const V3& color, unsigned pixelID) const {
+        V3 front = camFront;
+        V3 up(cam.up[0], cam.up[1], cam.up[2]);
+        V3 right = cross(front, up);
+        normalize(right);
+        V3 orthoUp = cross(right, front);
+        int x = pixelID % cam.width;
+        int y = pixelID / cam.width;
+        V3 dir = front * float(cam.sight_dist) + right * float(x + 0.5 - (cam.width / 2.0)) +
+                 orthoUp * float((cam.height / 2.0) - 0.5 - y);
+        normalize(dir);
+        return color / std::abs(dot(dir, front));
+    }
+
+    // MCRenderer.cpp:149-218
+    void samplePath(std::vector<PRay>& path, PRay& prevRay, unsigned depth, Stream& rng) {
+        PRay termRay;
+        termRay.origin = prevRay.origin;
+        termRay.direction = V3(0, 0, 0);
+        termRay.color = V3(0, 0, 0);
+        termRay.directionProb = 1;
+        termRay.insideObject = termRay.contactObject = termRay.intersectObject = -1;
+
+        path.push_back(prevRay);
+        PRay nextRay;
+        if (prevRay.insideObject >= 0) {
+            nextRay = scatter(prevRay.insideObject, prevRay, rng);
+        } else if (prevRay.intersectObject >= 0) {
+            nextRay = scatter(prevRay.intersectObject, prevRay, rng);
+        } else {
+            path.push_back(termRay);
+            return;
+        }
+        if (length(nextRay.direction) < 0.5) {
+            path.push_back(nextRay);
+            return;
+        }
+        if (depth + 1 > maxDepth) {
+            path.push_back(termRay);
+            return;
+        }
+        Condition cond;
+        cond.mode = 2;
+        cond.contact = nextRay.contactObject;
+        cond.inside = nextRay.insideObject;
+        int oid = -1;
+        unsigned lt = 0;
+        float dist = sceneIntersect(nextRay, &cond, oid, lt);
+        if (dist < 0) {
+            path.push_back(nextRay);
+            path.push_back(termRay);
+            return;
+        }
+        nextRay.intersectObject = oid;
+        nextRay.intersectObjectTriangleID = lt;
+        nextRay.intersectDist = dist;
+        samplePath(path, nextRay, depth + 1, rng);
+    }
+
+    // PathTracer.cpp:20-42 for one (pixel, sample); returns the vignetting-compensated radiance
+    V3 samplePixel(unsigned p, unsigned s, uint32_t seed, std::vector<PRay>& eyePath) {
+        Stream rng(seed, p, s);
+        eyePath.clear();
+        PRay start = generateRay(p, rng);
+        samplePath(eyePath, start, 0, rng);
+        if (!emissive(eyePath.back().contactObject)) return V3(0, 0, 0);
+        V3 color(1, 1, 1);
+        for (size_t i = 0; i < eyePath.size(); i++) {
+            color = color * (eyePath[i].color / eyePath[i].directionProb / eyePath[i].originProb);
+            if (i != eyePath.size() - 1) {
+                color = color * cosineTerm(eyePath[i]);
+                float dist = length(eyePath[i + 1].origin - eyePath[i].origin);
+                color = color * radianceDecay(eyePath[i], dist);
+            }
+        }
+        return eliminateVignetting(color, p);
+    }
+};
+
+}  // namespace
+
+// ---- C ABI ----------------------------------------------------------------------------------------
+extern "C" {
+
+OrcScene* orc_scene_create(int32_t n_verts, const float* verts, int32_t n_tris, const uint32_t* tris,
+                           const int32_t* tri_obj, const int32_t* tri_local, const float* tri_vn,
+                           int32_t n_objects, const OrcObject* objects) {
+    OrcScene* S = new OrcScene;
+    S->verts.resize(n_verts);
+    for (int i = 0; i < n_verts; i++) S->verts[i] = V3(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+    S->tris.resize(n_tris);
+    for (int i = 0; i < n_tris; i++)
+        for (int k = 0; k < 3; k++) S->tris[i].v[k] = tris[3 * i + k];
+    S->triObj.assign(tri_obj, tri_obj + n_tris);
+    S->triLocal.assign(tri_local, tri_local + n_tris);
+    if (tri_vn) {
+        S->triVn.resize(3 * (size_t)n_tris);
+        for (size_t i = 0; i < 3 * (size_t)n_tris; i++)
+            S->triVn[i] = V3(tri_vn[3 * i], tri_vn[3 * i + 1], tri_vn[3 * i + 2]);
+    }
+    S->objects.assign(objects, objects + n_objects);
+    // KDTree::build(BEST), KDTree.cpp:230-246
+    S->root = new Node;
+    for (int i = 0; i < n_tris; i++) S->root->triangleIndices.push_back(i);
+    int md = 0;
+    splitBest(*S, S->root, 0, md);
+    S->depth = md;
+    if (n_tris > 0) flattenNode(*S, S->root);
+    return S;
+}
+
+void orc_scene_destroy(OrcScene* s) {
+    if (!s) return;
+    destroyNode(s->root);
+    delete s;
+}
+
+int32_t orc_tree_num_nodes(const OrcScene* s) { return (int32_t)s->fright.size(); }
+int32_t orc_tree_depth(const OrcScene* s) { return s->depth; }
+
+void orc_tree_flatten(const OrcScene* s, float* node_min, float* node_max, int32_t* node_right,
+                      int32_t* leaf_begin, int32_t* leaf_end, int32_t* slot_tid) {
+    size_t n = s->fright.size();
+    for (size_t i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) {
+            node_min[3 * i + c] = s->fmin[i][c];
+            node_max[3 * i + c] = s->fmax[i][c];
+        }
+        node_right[i] = s->fright[i];
+        leaf_begin[i] = s->fbegin[i];
+        leaf_end[i] = s->fend[i];
+    }
+    std::copy(s->slotTid.begin(), s->slotTid.end(), slot_tid);
+}
+
+static inline KRay loadRay(const float* o, const float* d, size_t n, size_t i) {
+    KRay r;
+    r.origin = V3(o[i], o[n + i], o[2 * n + i]);
+    r.direction = V3(d[i], d[n + i], d[2 * n + i]);
+    return r;
+}
+
+void orc_intersect(const OrcScene* s, const float* origins, const float* directions,
+                   const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
+                   int threads) {
+    (void)threads;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads > 0 ? threads : 1)
+    for (long long i = 0; i < (long long)n; i++) {
+        KRay r = loadRay(origins, directions, n, (size_t)i);
+        Condition c = makeCond(mode, aux ? aux[i] : 0);
+        unsigned tid = 0;
+        float t = s->root ? nodeIntersect(*s, r, s->root, tid, mode ? &c : nullptr, nullptr) : -1;
+        t_out[i] = t >= 0 ? t : -1.f;
+        tid_out[i] = t >= 0 ? (int32_t)tid : -1;
+    }
+}
+
+void orc_intersect_ref_counts(const OrcScene* s, const float* origins, const float* directions,
+                              const int32_t* aux, size_t n, int mode, uint64_t* n_box,
+                              uint64_t* n_tri) {
+    Counters cnt;
+    for (size_t i = 0; i < n; i++) {
+        KRay r = loadRay(origins, directions, n, i);
+        Condition c = makeCond(mode, aux ? aux[i] : 0);
+        unsigned tid = 0;
+        if (s->root) nodeIntersect(*s, r, s->root, tid, mode ? &c : nullptr, &cnt);
+    }
+    *n_box = cnt.box;
+    *n_tri = cnt.tri;
+}
+
+void orc_intersect_ordered(const OrcScene* s, const float* origins, const float* directions,
+                           const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
+                           uint64_t* n_box, uint64_t* n_tri) {
+    Counters cnt;
+    for (size_t i = 0; i < n; i++) {
+        KRay r = loadRay(origins, directions, n, i);
+        Condition c = makeCond(mode, aux ? aux[i] : 0);
+        int slot = -1;
+        float t = s->root ? orderedIntersect(*s, r, c, slot, cnt) : -1;
+        if (t_out) t_out[i] = slot >= 0 ? t : -1.f;
+        if (tid_out) tid_out[i] = slot >= 0 ? s->slotTid[slot] : -1;
+    }
+    if (n_box) *n_box = cnt.box;
+    if (n_tri) *n_tri = cnt.tri;
+}
+
+float orc_box_intersect(const float bmin[3], const float bmax[3], const float o[3], const float d[3]) {
+    KRay r;
+    r.origin = V3(o[0], o[1], o[2]);
+    r.direction = V3(d[0], d[1], d[2]);
+    return boxIntersect(V3(bmin[0], bmin[1], bmin[2]), V3(bmax[0], bmax[1], bmax[2]), r);
+}
+
+float orc_tri_intersect(const float v0[3], const float v1[3], const float v2[3], const float o[3],
+                        const float d[3]) {
+    OrcScene S;
+    S.verts = {V3(v0[0], v0[1], v0[2]), V3(v1[0], v1[1], v1[2]), V3(v2[0], v2[1], v2[2])};
+    Tri t;
+    t.v[0] = 0;
+    t.v[1] = 1;
+    t.v[2] = 2;
+    S.tris.push_back(t);
+    KRay r;
+    r.origin = V3(o[0], o[1], o[2]);
+    r.direction = V3(d[0], d[1], d[2]);
+    return triIntersect(S, r, 0, nullptr);
+}
+
+void orc_world_normal(const OrcScene* s, int32_t tid, const float pos[3], float n_out[3]) {
+    V3 n = worldNormal(*s, (unsigned)tid, V3(pos[0], pos[1], pos[2]));
+    n_out[0] = n.x;
+    n_out[1] = n.y;
+    n_out[2] = n.z;
+}
+
+int orc_legal(const OrcScene* s, int32_t tid, const float o[3], const float d[3], float dist,
+              int32_t contact, int32_t inside) {
+    Condition c;
+    c.mode = 2;
+    c.contact = contact;
+    c.inside = inside;
+    KRay r;
+    r.origin = V3(o[0], o[1], o[2]);
+    r.direction = V3(d[0], d[1], d[2]);
+    return c.legal(*s, r, (unsigned)tid, dist) ? 1 : 0;
+}
+
+uint32_t orc_rng_draw(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t dim) {
+    Stream st(seed, pixel, sample);
+    st.ctr = dim;
+    return st.bits();
+}
+
+void orc_camera_ray(const OrcCamera* cam, uint32_t pixel, float u, float v, float dir_out[3]) {
+    V3 pos(cam->position[0], cam->position[1], cam->position[2]);
+    V3 front = V3(cam->focus[0], cam->focus[1], cam->focus[2]) - pos;
+    normalize(front);
+    V3 up(cam->up[0], cam->up[1], cam->up[2]);
+    V3 right = cross(front, up);
+    normalize(right);
+    V3 orthoUp = cross(right, front);
+    int x = pixel % cam->width;
+    int y = pixel / cam->width;
+    V3 dir = front * float(cam->sight_dist) + right * float(x + u - (cam->width / 2.0)) +
+             orthoUp * float((cam->height / 2.0) - v - y);
+    normalize(dir);
+    dir_out[0] = dir.x;
+    dir_out[1] = dir.y;
+    dir_out[2] = dir.z;
+}
+
+void orc_hemi_cos(float expTerm, float u1, float u2, float out[3]) {
+    V3 r = Tracer::hemiCos(expTerm, u1, u2);
+    out[0] = r.x;
+    out[1] = r.y;
+    out[2] = r.z;
+}
+
+void orc_render_pt(const OrcScene* s, const OrcCamera* cam, uint32_t spp_begin, uint32_t spp_count,
+                   uint32_t max_depth, uint32_t seed, float* rgb_sum, uint64_t* n_rays, int threads) {
+    int npix = cam->width * cam->height;
+    std::fill(rgb_sum, rgb_sum + 3 * (size_t)npix, 0.f);
+    uint64_t total = 0;
+#pragma omp parallel num_threads(threads > 0 ? threads : 1) reduction(+ : total)
+    {
+        Tracer tr(*s, *cam, max_depth);
+        std::vector<PRay> path;
+#pragma omp for schedule(dynamic, 64)
+        for (int p = 0; p < npix; p++) {
+            float acc[3] = {0, 0, 0};
+            for (uint32_t k = 0; k < spp_count; k++) {
+                V3 c = tr.samplePixel((unsigned)p, spp_begin + k, seed, path);
+                acc[0] += c.x;
+                acc[1] += c.y;
+                acc[2] += c.z;
+            }
+            rgb_sum[3 * p] = acc[0];
+            rgb_sum[3 * p + 1] = acc[1];
+            rgb_sum[3 * p + 2] = acc[2];
+        }
+        total += tr.nRays;
+    }
+    if (n_rays) *n_rays = total;
+}
+
+int32_t orc_trace_path(const OrcScene* s, const OrcCamera* cam, uint32_t pixel, uint32_t sample,
+                       uint32_t max_depth, uint32_t seed, float* verts, int32_t cap, float rgb[3]) {
+    Tracer tr(*s, *cam, max_depth);
+    std::vector<PRay> path;
+    V3 c = tr.samplePixel(pixel, sample, seed, path);
+    rgb[0] = c.x;
+    rgb[1] = c.y;
+    rgb[2] = c.z;
+    int32_t n = (int32_t)path.size();
+    for (int32_t i = 0; i < n && i < cap; i++) {
+        float* o = verts + 10 * i;
+        o[0] = path[i].origin.x; o[1] = path[i].origin.y; o[2] = path[i].origin.z;
+        o[3] = path[i].direction.x; o[4] = path[i].direction.y; o[5] = path[i].direction.z;
+        o[6] = path[i].color.x; o[7] = path[i].color.y; o[8] = path[i].color.z;
+        o[9] = path[i].directionProb;
+    }
+    return n;
+}
+
+}  // extern "C"

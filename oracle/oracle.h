@@ -1,0 +1,105 @@
+/* oracle.h — C ABI of liboracle.so: a CPU restatement of the reference algorithm for the hot path
+ * (closest-hit over the "KDTree" + the PathTracer sample loop).
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing in the product (renderer_amd/, libmirt.so) links, loads or
+ * calls this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, as the
+ * checker. It is deliberately written in the reference's own shape (pointer tree, recursive
+ * both-children traversal, recursive samplePath with a stored vertex list) so that it can be read
+ * side by side with the reference files each function cites.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or images for this path
+ * (SURVEY.md §4), and its sources cannot be compiled in this image without writing stand-in
+ * headers (every .cpp includes the MSVC precompiled header "StdAfx.h" -> <tchar.h>,
+ * <SDKDDKVer.h>; the integrator base needs OpenCV and <io.h>), so there is no oracle/_ref.
+ * The restatement is checked only against hand-derived known answers and its own invariants.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_DIFFUSE 0
+#define ORC_GLOSSY 1
+#define ORC_REFRACTIVE 2
+#define ORC_EMISSIVE 3
+#define ORC_VPM 4
+
+typedef struct OrcObject {
+    int32_t type, has_vn, volumetric, tri_begin, tri_count;
+    float color[3];
+    float coeff;
+    float ior;
+    float decay[3];
+    float sigma_s[3];
+    float sigma_a[3];
+    float g;
+} OrcObject;
+
+typedef struct OrcCamera {
+    int32_t width, height;
+    uint32_t sight_dist;
+    float position[3], focus[3], up[3];
+} OrcCamera;
+
+typedef struct OrcScene OrcScene;
+
+/* Raw (pre-tree) scene: world-space vertices, global-index triangles (Scene.cpp:248-273). */
+OrcScene* orc_scene_create(int32_t n_verts, const float* verts, int32_t n_tris,
+                           const uint32_t* tris, const int32_t* tri_obj, const int32_t* tri_local,
+                           const float* tri_vn /* [T*9] or NULL */, int32_t n_objects,
+                           const OrcObject* objects);
+void orc_scene_destroy(OrcScene* s);
+
+/* tree facts + pre-order flatten (KDTree.cpp:346-383) */
+int32_t orc_tree_num_nodes(const OrcScene* s);
+int32_t orc_tree_depth(const OrcScene* s);
+void orc_tree_flatten(const OrcScene* s, float* node_min, float* node_max, int32_t* node_right,
+                      int32_t* leaf_begin, int32_t* leaf_end, int32_t* slot_tid);
+
+/* reference closest hit (recursive, both children, KDTree.cpp:295-339); rays plane-major
+ * float[3][n]; mode 0 unconditional, 1 skip aux==tid (Intersection.frag:63-64), 2 NoSelfIntersection
+ * with aux = (contact+1)|((inside+1)<<16). threads: OpenMP threads over rays (1 = serial).       */
+void orc_intersect(const OrcScene* s, const float* origins, const float* directions,
+                   const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
+                   int threads);
+/* per-ray visit counters of the REFERENCE traversal order (both children, no pruning) */
+void orc_intersect_ref_counts(const OrcScene* s, const float* origins, const float* directions,
+                              const int32_t* aux, size_t n, int mode, uint64_t* n_box,
+                              uint64_t* n_tri);
+/* restatement of the PRODUCT's traversal order (near-first, distance-pruned) used only to count
+ * node-box and triangle tests for the algorithmic-bytes figure; also returns hits.             */
+void orc_intersect_ordered(const OrcScene* s, const float* origins, const float* directions,
+                           const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
+                           uint64_t* n_box, uint64_t* n_tri);
+
+/* known-answer entry points for single functions */
+float orc_box_intersect(const float bmin[3], const float bmax[3], const float o[3],
+                        const float d[3]); /* KDTree.cpp:34-52 */
+float orc_tri_intersect(const float v0[3], const float v1[3], const float v2[3], const float o[3],
+                        const float d[3]); /* KDTree.cpp:267-293, no condition */
+void orc_world_normal(const OrcScene* s, int32_t tid, const float pos[3],
+                      float n_out[3]); /* SimpleShape.cpp:300-339 via SceneObject.cpp:250-254 */
+int orc_legal(const OrcScene* s, int32_t tid, const float o[3], const float d[3], float dist,
+              int32_t contact, int32_t inside); /* NoSelfIntersectionCondition.cpp:12-27 */
+uint32_t orc_rng_draw(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t dim);
+void orc_camera_ray(const OrcCamera* cam, uint32_t pixel, float u, float v, float dir_out[3]);
+void orc_hemi_cos(float expTerm, float u1, float u2, float out[3]); /* RandGenerator.cpp:152-168 */
+
+/* PathTracer (PathTracer.cpp:12-44 + MCRenderer.cpp:149-224); rgb_sum[W*H*3] receives the SUM over
+ * samples [spp_begin, spp_begin+spp_count); counter RNG keyed (seed, pixel, sample, dim).
+ * n_rays (may be NULL): closest-hit queries issued. threads: OpenMP over pixels.               */
+void orc_render_pt(const OrcScene* s, const OrcCamera* cam, uint32_t spp_begin, uint32_t spp_count,
+                   uint32_t max_depth, uint32_t seed, float* rgb_sum, uint64_t* n_rays,
+                   int threads);
+/* one path, verbose: writes up to cap vertices (origin xyz, dir xyz, color rgb, dirProb) = 10
+ * floats each; returns the vertex count and the path's contribution in rgb[3].                 */
+int32_t orc_trace_path(const OrcScene* s, const OrcCamera* cam, uint32_t pixel, uint32_t sample,
+                       uint32_t max_depth, uint32_t seed, float* verts, int32_t cap, float rgb[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

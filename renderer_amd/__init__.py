@@ -1,0 +1,318 @@
+"""renderer_amd — ctypes bindings of libmirt.so (include/mirt.h, include/mirt_host.h).
+
+The package holds only what the hot path needs: the HIP kernels + C-ABI (csrc/), the C++ host
+surface that mirrors the reference's Scene / ConfigManager / Renderer (host/), and these bindings,
+which tests and bench.py use. There is no CPU implementation of the path here: without the built
+library, or without a GPU, the compute calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmirt.so")
+REPO_ROOT = os.path.dirname(_HERE)
+DATA_DIR = os.path.join(REPO_ROOT, "Data")
+
+OBJ_DIFFUSE, OBJ_GLOSSY, OBJ_REFRACTIVE, OBJ_EMISSIVE, OBJ_VPM = range(5)
+MODE_UNCONDITIONAL, MODE_LAST_TID, MODE_NO_SELF = range(3)
+
+# MirtObject as a numpy structured dtype (same layout as the C struct; also the oracle's OrcObject)
+OBJECT_DTYPE = np.dtype(
+    [("type", "<i4"), ("has_vn", "<i4"), ("volumetric", "<i4"), ("tri_begin", "<i4"), ("tri_count", "<i4"),
+     ("color", "<f4", 3), ("coeff", "<f4"), ("ior", "<f4"), ("decay", "<f4", 3), ("sigma_s", "<f4", 3),
+     ("sigma_a", "<f4", 3), ("g", "<f4")], align=False)
+assert OBJECT_DTYPE.itemsize == 80
+
+
+class Camera(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("sight_dist", C.c_uint32),
+                ("position", C.c_float * 3), ("focus", C.c_float * 3), ("up", C.c_float * 3)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("camera", Camera), ("spp_begin", C.c_uint32), ("spp_count", C.c_uint32),
+                ("max_depth", C.c_uint32), ("seed", C.c_uint32), ("spp_per_launch", C.c_uint32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("n_samples", C.c_uint64), ("n_rays", C.c_uint64), ("gpu_ms", C.c_double),
+                ("intersect_ms", C.c_double)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_nodes", C.c_int32), ("node_min", C.c_void_p),
+                ("node_max", C.c_void_p), ("node_right", C.c_void_p), ("node_leaf_begin", C.c_void_p),
+                ("node_leaf_end", C.c_void_p), ("n_tris", C.c_int32), ("slot_tid", C.c_void_p),
+                ("tri_pos", C.c_void_p), ("tri_obj", C.c_void_p), ("tri_local", C.c_void_p),
+                ("tri_vn", C.c_void_p), ("n_objects", C.c_int32), ("objects", C.c_void_p)]
+
+
+# every symbol include/mirt.h and include/mirt_host.h declare (checked by the CPU tests)
+MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_scene", "mirt_intersect",
+                "mirt_intersect_dev", "mirt_intersect_count_dev", "mirt_generate_rays_dev", "mirt_render_pt",
+                "mirt_render_pt_dev", "mirt_capture_rays_dev", "mirt_device_info"]
+MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_free",
+                 "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
+                 "mirth_describe", "mirth_upload", "mirth_render", "mirth_fill_intersect", "mirth_shutdown",
+                 "mirth_save_pfm", "mirth_load_pfm"]
+
+_lib = None
+
+
+def lib():
+    """Loads libmirt.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("renderer_amd: %s is missing; build it with `make -C renderer_amd` "
+                               "(or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.mirt_last_error.restype = C.c_char_p
+        L.mirt_last_error.argtypes = [C.c_void_p]
+        L.mirth_last_error.restype = C.c_char_p
+        for name in MIRT_SYMBOLS + MIRTH_SYMBOLS:
+            fn = getattr(L, name)
+            if name not in ("mirt_last_error", "mirth_last_error", "mirth_free", "mirth_shutdown"):
+                fn.restype = C.c_int
+        L.mirth_free.restype = None
+        L.mirth_free.argtypes = [C.c_void_p]
+        L.mirth_shutdown.restype = None
+        L.mirt_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.mirt_destroy.argtypes = [C.c_void_p]
+        L.mirt_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        L.mirt_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                     C.c_void_p, C.c_void_p]
+        L.mirt_intersect_dev.argtypes = L.mirt_intersect.argtypes + [C.c_void_p]
+        L.mirt_intersect_count_dev.argtypes = L.mirt_intersect.argtypes + [C.POINTER(C.c_uint64),
+                                                                          C.POINTER(C.c_uint64)]
+        L.mirt_generate_rays_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_void_p, C.c_void_p]
+        L.mirt_render_pt.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
+        L.mirt_render_pt_dev.argtypes = L.mirt_render_pt.argtypes
+        L.mirt_capture_rays_dev.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.POINTER(C.c_size_t)]
+        L.mirt_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.mirth_load_config.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.mirth_scene_from_arrays.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mirth_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int32 * 5)]
+        L.mirth_get_raw.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.mirth_get_tree.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.mirth_get_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
+        L.mirth_get_render_cfg.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 3)]
+        L.mirth_describe.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        L.mirth_upload.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mirth_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(RenderStats)]
+        L.mirth_fill_intersect.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 8
+        L.mirth_save_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.mirth_load_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32 * 2)]
+        _lib = L
+    return _lib
+
+
+class MirtError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HostScene:
+    """A scene on the host: loaded from a config (ConfigManager::load) or made from arrays."""
+
+    def __init__(self, handle):
+        self.h = handle
+        cnt = (C.c_int32 * 5)()
+        lib().mirth_counts(self.h, C.byref(cnt))
+        self.n_verts, self.n_tris, self.n_objects, self.n_nodes, self.depth = list(cnt)
+
+    @staticmethod
+    def load_config(path):
+        h = C.c_void_p()
+        if lib().mirth_load_config(os.fsencode(path), C.byref(h)) != 0:
+            raise MirtError(lib().mirth_last_error().decode())
+        return HostScene(h)
+
+    @staticmethod
+    def from_arrays(verts, tris, tri_obj, objects, tri_vn=None):
+        verts = np.ascontiguousarray(verts, np.float32)
+        tris = np.ascontiguousarray(tris, np.uint32)
+        tri_obj = np.ascontiguousarray(tri_obj, np.int32)
+        objects = np.ascontiguousarray(objects, OBJECT_DTYPE)
+        if tri_vn is not None:
+            tri_vn = np.ascontiguousarray(tri_vn, np.float32)
+        h = C.c_void_p()
+        rc = lib().mirth_scene_from_arrays(len(verts), _ptr(verts), len(tris), _ptr(tris), _ptr(tri_obj),
+                                           _ptr(tri_vn), len(objects), _ptr(objects), C.byref(h))
+        if rc != 0:
+            raise MirtError(lib().mirth_last_error().decode())
+        return HostScene(h)
+
+    def close(self):
+        if self.h:
+            lib().mirth_free(self.h)
+            self.h = None
+
+    def raw(self):
+        """dict of the pre-tree scene arrays (world-space)."""
+        V, T, O = self.n_verts, self.n_tris, self.n_objects
+        out = dict(verts=np.empty((V, 3), np.float32), tris=np.empty((T, 3), np.uint32),
+                   tri_obj=np.empty(T, np.int32), tri_local=np.empty(T, np.int32),
+                   tri_vn=np.empty((T, 9), np.float32), objects=np.empty(O, OBJECT_DTYPE))
+        lib().mirth_get_raw(self.h, _ptr(out["verts"]), _ptr(out["tris"]), _ptr(out["tri_obj"]),
+                            _ptr(out["tri_local"]), _ptr(out["tri_vn"]), _ptr(out["objects"]))
+        return out
+
+    def tree(self):
+        N, T = self.n_nodes, self.n_tris
+        out = dict(node_min=np.empty((N, 3), np.float32), node_max=np.empty((N, 3), np.float32),
+                   node_right=np.empty(N, np.int32), leaf_begin=np.empty(N, np.int32),
+                   leaf_end=np.empty(N, np.int32), slot_tid=np.empty(T, np.int32))
+        lib().mirth_get_tree(self.h, _ptr(out["node_min"]), _ptr(out["node_max"]), _ptr(out["node_right"]),
+                             _ptr(out["leaf_begin"]), _ptr(out["leaf_end"]), _ptr(out["slot_tid"]))
+        return out
+
+    def camera(self):
+        cam = Camera()
+        lib().mirth_get_camera(self.h, C.byref(cam))
+        return cam
+
+    def render_cfg(self):
+        out = (C.c_uint32 * 3)()
+        lib().mirth_get_render_cfg(self.h, C.byref(out))
+        return dict(max_depth=out[0], spp=out[1], seed=out[2])
+
+    def describe(self):
+        d = SceneDesc()
+        lib().mirth_describe(self.h, C.byref(d))
+        return d
+
+    def upload(self):
+        """Scene::buildKDTree's device step; returns a Device bound to the service's context."""
+        ctx = C.c_void_p()
+        if lib().mirth_upload(self.h, C.byref(ctx)) != 0:
+            raise MirtError(lib().mirth_last_error().decode())
+        return Device(ctx, owned=False)
+
+    def render(self, spp=0, seed=0):
+        cam = self.camera()
+        img = np.zeros((cam.height, cam.width, 3), np.float32)
+        st = RenderStats()
+        if lib().mirth_render(self.h, spp, seed, _ptr(img), C.byref(st)) != 0:
+            raise MirtError(lib().mirth_last_error().decode())
+        return img, st
+
+    def fill_intersect(self, o, d, contact, inside):
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        n = len(o)
+        contact = np.ascontiguousarray(contact, np.int32)
+        inside = np.ascontiguousarray(inside, np.int32)
+        dist = np.empty(n, np.float32)
+        tid, obj, local = (np.empty(n, np.int32) for _ in range(3))
+        if lib().mirth_fill_intersect(self.h, n, _ptr(o), _ptr(d), _ptr(contact), _ptr(inside), _ptr(dist),
+                                      _ptr(tid), _ptr(obj), _ptr(local)) != 0:
+            raise MirtError(lib().mirth_last_error().decode())
+        return dist, tid, obj, local
+
+
+def pack_ids(contact, inside):
+    contact = np.asarray(contact, np.int64)
+    inside = np.asarray(inside, np.int64)
+    return (((contact + 1) & 0xFFFF) | (((inside + 1) & 0xFFFF) << 16)).astype(np.uint32).view(np.int32)
+
+
+class Device:
+    """One MirtContext (one GPU)."""
+
+    def __init__(self, ctx=None, device=0, owned=True):
+        self.owned = owned
+        if ctx is None:
+            ctx = C.c_void_p()
+            rc = lib().mirt_create(device, C.byref(ctx))
+            if rc != 0:
+                raise MirtError("mirt_create failed (%d): %s" % (rc, lib().mirt_last_error(None).decode()))
+        self.ctx = ctx
+
+    def close(self):
+        if self.owned and self.ctx:
+            lib().mirt_destroy(self.ctx)
+        self.ctx = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MirtError("mirt error %d: %s" % (rc, lib().mirt_last_error(self.ctx).decode()))
+
+    def info(self):
+        buf = C.create_string_buffer(512)
+        self._check(lib().mirt_device_info(self.ctx, buf, 512))
+        return buf.value.decode()
+
+    def upload(self, desc):
+        self._check(lib().mirt_upload_scene(self.ctx, C.byref(desc)))
+
+    def intersect(self, origins, directions, aux=None, mode=MODE_UNCONDITIONAL):
+        """origins, directions: float32 [3, n] plane-major (host). Returns (t[n], tid[n])."""
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(directions, np.float32)
+        assert o.ndim == 2 and o.shape[0] == 3 and o.shape == d.shape
+        n = o.shape[1]
+        a = None if aux is None else np.ascontiguousarray(aux, np.int32)
+        t = np.empty(n, np.float32)
+        tid = np.empty(n, np.int32)
+        self._check(lib().mirt_intersect(self.ctx, _ptr(o), _ptr(d), _ptr(a), n, mode, _ptr(t), _ptr(tid)))
+        return t, tid
+
+    def intersect_dev(self, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr, stream=None):
+        self._check(lib().mirt_intersect_dev(self.ctx, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr, stream))
+
+    def intersect_count_dev(self, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr):
+        nb, nt = C.c_uint64(), C.c_uint64()
+        self._check(lib().mirt_intersect_count_dev(self.ctx, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr,
+                                                   C.byref(nb), C.byref(nt)))
+        return nb.value, nt.value
+
+    def generate_rays_dev(self, cam, spp_begin, spp_count, seed, o_ptr, d_ptr):
+        self._check(lib().mirt_generate_rays_dev(self.ctx, C.byref(cam), spp_begin, spp_count, seed, o_ptr, d_ptr))
+
+    def render_pt(self, cam, spp_count, spp_begin=0, max_depth=20, seed=1, spp_per_launch=0):
+        """Returns (rgb_sum [H, W, 3] float32 on the host, RenderStats)."""
+        p = RenderParams(cam, spp_begin, spp_count, max_depth, seed, spp_per_launch)
+        img = np.zeros((cam.height, cam.width, 3), np.float32)
+        st = RenderStats()
+        self._check(lib().mirt_render_pt(self.ctx, C.byref(p), _ptr(img), C.byref(st)))
+        return img, st
+
+    def render_pt_dev(self, cam, rgb_sum_ptr, spp_count, spp_begin=0, max_depth=20, seed=1, spp_per_launch=0):
+        p = RenderParams(cam, spp_begin, spp_count, max_depth, seed, spp_per_launch)
+        st = RenderStats()
+        self._check(lib().mirt_render_pt_dev(self.ctx, C.byref(p), rgb_sum_ptr, C.byref(st)))
+        return st
+
+    def capture_rays_dev(self, cam, spp_count, depth_lo, depth_hi, o_ptr, d_ptr, aux_ptr, capacity,
+                         spp_begin=0, max_depth=20, seed=1):
+        p = RenderParams(cam, spp_begin, spp_count, max_depth, seed, 0)
+        n = C.c_size_t()
+        self._check(lib().mirt_capture_rays_dev(self.ctx, C.byref(p), depth_lo, depth_hi, o_ptr, d_ptr, aux_ptr,
+                                                capacity, C.byref(n)))
+        return n.value
+
+
+def make_camera(width, height, sight_dist, position=(0, 0, 2), focus=(0, 0, 0), up=(0, 1, 0)):
+    c = Camera()
+    c.width, c.height, c.sight_dist = width, height, sight_dist
+    c.position[:] = position
+    c.focus[:] = focus
+    c.up[:] = up
+    return c
+
+
+def shard_samples(spp_total, world_size, rank):
+    """Contiguous sample-index shard of rank `rank`: [begin, begin+count)."""
+    base, rem = divmod(spp_total, world_size)
+    begin = rank * base + min(rank, rem)
+    return begin, base + (1 if rank < rem else 0)

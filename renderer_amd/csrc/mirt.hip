@@ -1,0 +1,707 @@
+// mirt.hip — C-ABI implementation of libmirt.so (see include/mirt.h). gfx950 / MI355X only.
+// Host side: context, scene upload (flattened tree -> HBM records), launch logic of the
+// generate -> intersect -> shade(+compact) wavefront loop. No CPU fallback exists: every compute
+// entry point fails with MIRT_E_NO_DEVICE / MIRT_E_HIP when there is no GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "intersect_kernels.h"
+#include "pt_kernels.h"
+
+#pragma clang fp contract(off)
+
+using namespace mirt;
+
+struct MirtContext {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string info;
+    // scene
+    NodeRec* d_nodes = nullptr;
+    TriRec* d_tris = nullptr;
+    VnRec* d_vns = nullptr;
+    DevObject* d_objs = nullptr;
+    DevScene sc{};
+    bool has_scene = false;
+    bool has_unsupported = false;  // scene holds an object kind the shade kernel cannot scatter yet
+    int block = 256;
+    size_t lds = 0;
+    // wavefront path state
+    PathBuf pb[2]{};
+    size_t pb_cap = 0;
+    float* d_L = nullptr;
+    uint32_t* d_cnt = nullptr;   // [2] live-path counters (ping-pong)
+    uint32_t* h_cnt = nullptr;   // pinned
+    unsigned long long* d_counters = nullptr;  // [2] box / triangle test counters
+    // staging for the host-pointer intersect
+    float* st_o = nullptr;
+    float* st_d = nullptr;
+    int* st_aux = nullptr;
+    float* st_t = nullptr;
+    int* st_id = nullptr;
+    size_t st_cap = 0;
+    std::vector<hipEvent_t> events;
+};
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                    \
+            return MIRT_E_HIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+static int fail(MirtContext* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// ---- host copies of the exact-arithmetic helpers (fp32, no contraction) --------------------------
+namespace {
+struct h3 {
+    float x, y, z;
+};
+inline h3 hsub(h3 a, h3 b) { return h3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline h3 hcross(h3 l, h3 r) {
+    return h3{l.y * r.z - l.z * r.y, l.z * r.x - l.x * r.z, l.x * r.y - l.y * r.x};
+}
+inline float hdot(h3 a, h3 b) {
+    float r = a.x * b.x;
+    r = r + a.y * b.y;
+    r = r + a.z * b.z;
+    return r;
+}
+inline h3 hnormalize(h3 a) {
+    float r = sqrtf(hdot(a, a));
+    if (r > 0.f) return h3{a.x / r, a.y / r, a.z / r};
+    return a;
+}
+}  // namespace
+
+extern "C" {
+
+const char* mirt_last_error(const MirtContext* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+int mirt_create(int device, MirtContext** out) {
+    if (!out) {
+        g_create_err = "mirt_create: out is NULL";
+        return MIRT_E_INVALID;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("mirt_create: no HIP device (") +
+                       (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                       "); libmirt has no CPU path";
+        return MIRT_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_err = "mirt_create: device index out of range";
+        return MIRT_E_INVALID;
+    }
+    MirtContext* ctx = new MirtContext;
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_err = std::string("mirt_create: ") + hipGetErrorString(e);
+        delete ctx;
+        return MIRT_E_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s arch=%s CUs=%d LDS/block=%zu HBM=%.1f GiB", prop.name,
+                 prop.gcnArchName, prop.multiProcessorCount, (size_t)prop.sharedMemPerBlock,
+                 prop.totalGlobalMem / 1073741824.0);
+        ctx->info = buf;
+    }
+    if ((e = hipMalloc(&ctx->d_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipHostMalloc(&ctx->h_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc(&ctx->d_counters, 2 * sizeof(unsigned long long))) != hipSuccess) {
+        g_create_err = std::string("mirt_create: ") + hipGetErrorString(e);
+        delete ctx;
+        return MIRT_E_HIP;
+    }
+    *out = ctx;
+    return MIRT_OK;
+}
+
+static void free_scene(MirtContext* ctx) {
+    hipFree(ctx->d_nodes);
+    hipFree(ctx->d_tris);
+    hipFree(ctx->d_vns);
+    hipFree(ctx->d_objs);
+    ctx->d_nodes = nullptr;
+    ctx->d_tris = nullptr;
+    ctx->d_vns = nullptr;
+    ctx->d_objs = nullptr;
+    ctx->has_scene = false;
+}
+
+static void free_paths(MirtContext* ctx) {
+    for (int k = 0; k < 2; k++) {
+        PathBuf& p = ctx->pb[k];
+        hipFree(p.o); hipFree(p.d); hipFree(p.thr); hipFree(p.t); hipFree(p.slot);
+        hipFree(p.key); hipFree(p.ctr); hipFree(p.ids); hipFree(p.pid);
+        p = PathBuf{};
+    }
+    hipFree(ctx->d_L);
+    ctx->d_L = nullptr;
+    ctx->pb_cap = 0;
+}
+
+static void free_staging(MirtContext* ctx) {
+    hipFree(ctx->st_o); hipFree(ctx->st_d); hipFree(ctx->st_aux); hipFree(ctx->st_t);
+    hipFree(ctx->st_id);
+    ctx->st_o = ctx->st_d = ctx->st_t = nullptr;
+    ctx->st_aux = ctx->st_id = nullptr;
+    ctx->st_cap = 0;
+}
+
+int mirt_destroy(MirtContext* ctx) {
+    if (!ctx) return MIRT_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    free_paths(ctx);
+    free_staging(ctx);
+    for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
+    hipFree(ctx->d_cnt);
+    hipFree(ctx->d_counters);
+    if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MIRT_OK;
+}
+
+int mirt_device_info(MirtContext* ctx, char* buf, size_t buflen) {
+    if (!ctx || !buf || buflen == 0) return MIRT_E_INVALID;
+    snprintf(buf, buflen, "%s", ctx->info.c_str());
+    return MIRT_OK;
+}
+
+// Validates the flattened tree (every index a kernel will follow is range-checked here, on the
+// host, so a malformed description cannot fault the GPU) and returns its depth.
+static int validate_tree(const MirtSceneDesc* s, int* depth_out, std::string* why) {
+    const int N = s->n_nodes, T = s->n_tris;
+    std::vector<int> end(N, -1);  // one past the last node of the subtree rooted at i
+    // iterative pre-order walk: (node, depth)
+    std::vector<std::pair<int, int>> st;
+    st.push_back({0, 0});
+    int maxd = 0;
+    std::vector<char> seen(N, 0);
+    long long slots_seen = 0;
+    int expect = 0;  // pre-order: nodes must be visited in index order
+    while (!st.empty()) {
+        auto [i, d] = st.back();
+        st.pop_back();
+        if (i != expect) { *why = "nodes are not in pre-order"; return MIRT_E_INVALID; }
+        expect++;
+        if (i < 0 || i >= N || seen[i]) { *why = "node index out of range or revisited"; return MIRT_E_INVALID; }
+        seen[i] = 1;
+        maxd = std::max(maxd, d);
+        int r = s->node_right[i];
+        if (r < 0) {
+            int b = s->node_leaf_begin[i], e = s->node_leaf_end[i];
+            if (b < 0 || e < b || e > T) { *why = "leaf slot range out of bounds"; return MIRT_E_INVALID; }
+            if (b != slots_seen) { *why = "leaf slot ranges are not contiguous in pre-order"; return MIRT_E_INVALID; }
+            slots_seen = e;
+        } else {
+            if (r <= i + 1 || r >= N) { *why = "right child index out of range"; return MIRT_E_INVALID; }
+            st.push_back({r, d + 1});      // visited after the whole left subtree
+            st.push_back({i + 1, d + 1});
+        }
+    }
+    if (expect != N) { *why = "unreachable nodes"; return MIRT_E_INVALID; }
+    if (slots_seen != T) { *why = "leaves do not cover all triangle slots"; return MIRT_E_INVALID; }
+    *depth_out = maxd;
+    return MIRT_OK;
+}
+
+int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
+    if (!ctx) return MIRT_E_INVALID;
+    if (!s || s->struct_size != sizeof(MirtSceneDesc))
+        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: bad descriptor / struct_size");
+    if (s->n_nodes <= 0 || s->n_tris <= 0 || s->n_objects <= 0 || !s->node_min || !s->node_max ||
+        !s->node_right || !s->node_leaf_begin || !s->node_leaf_end || !s->slot_tid || !s->tri_pos ||
+        !s->tri_obj || !s->tri_local || !s->objects)
+        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: empty scene or NULL array");
+    if (s->n_objects > MIRT_MAX_OBJECTS)
+        return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: more than 65533 objects");
+    int depth = 0;
+    std::string why;
+    if (validate_tree(s, &depth, &why) != MIRT_OK)
+        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: " + why);
+    if (depth > MIRT_MAX_TREE_DEPTH)
+        return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: tree deeper than MIRT_MAX_TREE_DEPTH");
+    const int N = s->n_nodes, T = s->n_tris;
+    std::vector<char> tid_seen(T, 0);
+    bool any_vn = false, unsupported = false;
+    for (int o = 0; o < s->n_objects; o++) {
+        any_vn |= s->objects[o].has_vn != 0;
+        int ty = s->objects[o].type;
+        if (ty < MIRT_OBJ_DIFFUSE || ty > MIRT_OBJ_VPM)
+            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: unknown object type");
+        unsupported |= ty == MIRT_OBJ_VPM;
+    }
+    if (any_vn && !s->tri_vn)
+        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: has_vn set but tri_vn is NULL");
+    for (int k = 0; k < T; k++) {
+        int g = s->slot_tid[k];
+        if (g < 0 || g >= T || tid_seen[g])
+            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: slot_tid is not a permutation");
+        tid_seen[g] = 1;
+        if (s->tri_obj[g] < 0 || s->tri_obj[g] >= s->n_objects)
+            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: tri_obj out of range");
+    }
+
+    std::vector<NodeRec> nodes(N);
+    for (int i = 0; i < N; i++) {
+        int r = s->node_right[i];
+        int c0 = r >= 0 ? r : ~s->node_leaf_begin[i];
+        int c1 = r >= 0 ? 0 : s->node_leaf_end[i];
+        float f0, f1;
+        memcpy(&f0, &c0, 4);
+        memcpy(&f1, &c1, 4);
+        nodes[i].lo = make_float4(s->node_min[3 * i], s->node_min[3 * i + 1], s->node_min[3 * i + 2], f0);
+        nodes[i].hi = make_float4(s->node_max[3 * i], s->node_max[3 * i + 1], s->node_max[3 * i + 2], f1);
+    }
+    std::vector<TriRec> tris(T);
+    std::vector<VnRec> vns(T);
+    for (int k = 0; k < T; k++) {
+        int g = s->slot_tid[k];
+        const float* p = s->tri_pos + 9 * (size_t)g;
+        h3 v0{p[0], p[1], p[2]}, v1{p[3], p[4], p[5]}, v2{p[6], p[7], p[8]};
+        // KDTree.cpp:283-284: n = normalize(lines[0] x lines[1])
+        h3 n = hnormalize(hcross(hsub(v1, v0), hsub(v2, v1)));
+        tris[k].a = make_float4(v0.x, v0.y, v0.z, n.x);
+        tris[k].b = make_float4(v1.x, v1.y, v1.z, n.y);
+        tris[k].c = make_float4(v2.x, v2.y, v2.z, n.z);
+        float fo, fg;
+        int ob = s->tri_obj[g];
+        memcpy(&fo, &ob, 4);
+        memcpy(&fg, &g, 4);
+        const float* vn = s->tri_vn ? s->tri_vn + 9 * (size_t)g : nullptr;
+        vns[k].n0 = make_float4(vn ? vn[0] : 0.f, vn ? vn[1] : 0.f, vn ? vn[2] : 0.f, fo);
+        vns[k].n1 = make_float4(vn ? vn[3] : 0.f, vn ? vn[4] : 0.f, vn ? vn[5] : 0.f, fg);
+        vns[k].n2 = make_float4(vn ? vn[6] : 0.f, vn ? vn[7] : 0.f, vn ? vn[8] : 0.f, 0.f);
+    }
+    std::vector<DevObject> objs(s->n_objects);
+    for (int o = 0; o < s->n_objects; o++) {
+        const MirtObject& m = s->objects[o];
+        DevObject& d = objs[o];
+        d.type = m.type;
+        d.has_vn = m.has_vn;
+        d.volumetric = m.volumetric;
+        d.pad = 0;
+        for (int c = 0; c < 3; c++) {
+            d.color[c] = m.color[c];
+            d.decay[c] = m.decay[c];
+        }
+        d.coeff = m.coeff;
+        d.ior = m.ior;
+    }
+
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+    HIPCHK(ctx, hipMalloc(&ctx->d_nodes, sizeof(NodeRec) * (size_t)N));
+    HIPCHK(ctx, hipMalloc(&ctx->d_tris, sizeof(TriRec) * (size_t)T));
+    HIPCHK(ctx, hipMalloc(&ctx->d_vns, sizeof(VnRec) * (size_t)T));
+    HIPCHK(ctx, hipMalloc(&ctx->d_objs, sizeof(DevObject) * (size_t)s->n_objects));
+    HIPCHK(ctx, hipMemcpy(ctx->d_nodes, nodes.data(), sizeof(NodeRec) * (size_t)N, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_tris, tris.data(), sizeof(TriRec) * (size_t)T, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_vns, vns.data(), sizeof(VnRec) * (size_t)T, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_objs, objs.data(), sizeof(DevObject) * (size_t)s->n_objects, hipMemcpyHostToDevice));
+    ctx->sc.nodes = ctx->d_nodes;
+    ctx->sc.tris = ctx->d_tris;
+    ctx->sc.vns = ctx->d_vns;
+    ctx->sc.objects = ctx->d_objs;
+    ctx->sc.n_nodes = N;
+    ctx->sc.n_tris = T;
+    ctx->sc.n_objects = s->n_objects;
+    ctx->sc.depth = depth;
+    // per-lane stack: (depth+1) levels x (node index, entry distance) x block lanes, in LDS
+    ctx->block = (size_t)(depth + 1) * 8 * 256 <= 65536 ? 256 : 64;
+    ctx->lds = (size_t)(depth + 1) * 8 * ctx->block;
+    ctx->has_scene = true;
+    ctx->has_unsupported = unsupported;
+    return MIRT_OK;
+}
+
+}  // extern "C"
+
+// ---- launches -------------------------------------------------------------------------------------
+template <bool COUNT, bool SLOT_OUT>
+static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
+                            const int* aux, const uint32_t* n_ptr, uint32_t n_max, uint32_t stride,
+                            float* t_out, int* id_out) {
+    if (n_max == 0) return MIRT_OK;
+    dim3 block(ctx->block), grid((n_max + ctx->block - 1) / ctx->block);
+    unsigned long long* cnt = ctx->d_counters;
+    switch (mode) {
+        case MIRT_MODE_UNCONDITIONAL:
+            hipLaunchKernelGGL((k_intersect<MIRT_MODE_UNCONDITIONAL, COUNT, SLOT_OUT>), grid, block,
+                               ctx->lds, st, ctx->sc, O, D, aux, n_ptr, n_max, stride, t_out, id_out, cnt);
+            break;
+        case MIRT_MODE_LAST_TID:
+            hipLaunchKernelGGL((k_intersect<MIRT_MODE_LAST_TID, COUNT, SLOT_OUT>), grid, block,
+                               ctx->lds, st, ctx->sc, O, D, aux, n_ptr, n_max, stride, t_out, id_out, cnt);
+            break;
+        case MIRT_MODE_NO_SELF:
+            hipLaunchKernelGGL((k_intersect<MIRT_MODE_NO_SELF, COUNT, SLOT_OUT>), grid, block,
+                               ctx->lds, st, ctx->sc, O, D, aux, n_ptr, n_max, stride, t_out, id_out, cnt);
+            break;
+        default:
+            return fail(ctx, MIRT_E_INVALID, "intersect: unknown mode");
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return MIRT_OK;
+}
+
+static int check_intersect_args(MirtContext* ctx, const float* o, const float* d, const int32_t* aux,
+                                size_t n, int mode, float* t_out, int32_t* tid_out) {
+    if (!ctx) return MIRT_E_INVALID;
+    if (!ctx->has_scene) return fail(ctx, MIRT_E_NO_SCENE, "intersect: no scene uploaded");
+    if (mode < 0 || mode > 2) return fail(ctx, MIRT_E_INVALID, "intersect: unknown mode");
+    if (n == 0) return MIRT_OK;
+    if (!o || !d || !t_out || !tid_out || (mode != MIRT_MODE_UNCONDITIONAL && !aux))
+        return fail(ctx, MIRT_E_INVALID, "intersect: NULL buffer");
+    if (n > 0x7FFFFFFFull) return fail(ctx, MIRT_E_LIMIT, "intersect: more than 2^31-1 rays in one call");
+    return MIRT_OK;
+}
+
+extern "C" {
+
+int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* directions,
+                       const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
+                       void* stream) {
+    int rc = check_intersect_args(ctx, origins, directions, aux, n, mode, t_out, tid_out);
+    if (rc != MIRT_OK || n == 0) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    return launch_intersect<false, false>(ctx, st, mode, origins, directions, aux, nullptr, (uint32_t)n,
+                                          (uint32_t)n, t_out, tid_out);
+}
+
+int mirt_intersect_count_dev(MirtContext* ctx, const float* origins, const float* directions,
+                             const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
+                             uint64_t* n_box_tests, uint64_t* n_tri_tests) {
+    int rc = check_intersect_args(ctx, origins, directions, aux, n, mode, t_out, tid_out);
+    if (rc != MIRT_OK) return rc;
+    if (!n_box_tests || !n_tri_tests) return fail(ctx, MIRT_E_INVALID, "intersect_count: NULL counter");
+    *n_box_tests = *n_tri_tests = 0;
+    if (n == 0) return MIRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    rc = launch_intersect<true, false>(ctx, ctx->stream, mode, origins, directions, aux, nullptr,
+                                       (uint32_t)n, (uint32_t)n, t_out, tid_out);
+    if (rc != MIRT_OK) return rc;
+    unsigned long long h[2];
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_box_tests = h[0];
+    *n_tri_tests = h[1];
+    return MIRT_OK;
+}
+
+int mirt_intersect(MirtContext* ctx, const float* origins, const float* directions, const int32_t* aux,
+                   size_t n, int mode, float* t_out, int32_t* tid_out) {
+    int rc = check_intersect_args(ctx, origins, directions, aux, n, mode, t_out, tid_out);
+    if (rc != MIRT_OK || n == 0) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t CH = 1u << 24;  // rays per staged chunk
+    size_t cap = std::min(n, CH);
+    if (cap > ctx->st_cap) {
+        free_staging(ctx);
+        HIPCHK(ctx, hipMalloc(&ctx->st_o, 3 * cap * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&ctx->st_d, 3 * cap * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&ctx->st_aux, cap * sizeof(int)));
+        HIPCHK(ctx, hipMalloc(&ctx->st_t, cap * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&ctx->st_id, cap * sizeof(int)));
+        ctx->st_cap = cap;
+    }
+    hipStream_t st = ctx->stream;
+    for (size_t b = 0; b < n; b += CH) {
+        size_t m = std::min(CH, n - b);
+        for (int c = 0; c < 3; c++) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->st_o + c * m, origins + c * n + b, m * sizeof(float), hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->st_d + c * m, directions + c * n + b, m * sizeof(float), hipMemcpyHostToDevice, st));
+        }
+        if (mode != MIRT_MODE_UNCONDITIONAL)
+            HIPCHK(ctx, hipMemcpyAsync(ctx->st_aux, aux + b, m * sizeof(int), hipMemcpyHostToDevice, st));
+        rc = launch_intersect<false, false>(ctx, st, mode, ctx->st_o, ctx->st_d, ctx->st_aux, nullptr,
+                                            (uint32_t)m, (uint32_t)m, ctx->st_t, ctx->st_id);
+        if (rc != MIRT_OK) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(t_out + b, ctx->st_t, m * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(tid_out + b, ctx->st_id, m * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    return MIRT_OK;
+}
+
+}  // extern "C"
+
+// ---- camera + wavefront loop ------------------------------------------------------------------------
+static int make_camera(MirtContext* ctx, const MirtCamera* c, DevCamera* out) {
+    if (!c || c->width <= 0 || c->height <= 0)
+        return fail(ctx, MIRT_E_INVALID, "camera: width/height must be positive");
+    if ((uint64_t)c->width * (uint64_t)c->height > (1ull << 28))
+        return fail(ctx, MIRT_E_LIMIT, "camera: more than 2^28 pixels");
+    // Camera.cpp:6-10
+    h3 pos{c->position[0], c->position[1], c->position[2]};
+    h3 front = hnormalize(hsub(h3{c->focus[0], c->focus[1], c->focus[2]}, pos));
+    h3 right = hnormalize(hcross(front, h3{c->up[0], c->up[1], c->up[2]}));
+    h3 oup = hcross(right, front);
+    out->pos = f3{pos.x, pos.y, pos.z};
+    out->front = f3{front.x, front.y, front.z};
+    out->right = f3{right.x, right.y, right.z};
+    out->up = f3{oup.x, oup.y, oup.z};
+    out->width = c->width;
+    out->height = c->height;
+    out->sight = (float)c->sight_dist;
+    out->half_w = c->width / 2.0;
+    out->half_h = c->height / 2.0;
+    return MIRT_OK;
+}
+
+static int ensure_paths(MirtContext* ctx, size_t cap) {
+    if (cap <= ctx->pb_cap) return MIRT_OK;
+    free_paths(ctx);
+    for (int k = 0; k < 2; k++) {
+        PathBuf& p = ctx->pb[k];
+        HIPCHK(ctx, hipMalloc(&p.o, 3 * cap * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&p.d, 3 * cap * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&p.thr, 3 * cap * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&p.t, cap * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&p.slot, cap * sizeof(int)));
+        HIPCHK(ctx, hipMalloc(&p.key, cap * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc(&p.ctr, cap * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc(&p.ids, cap * sizeof(int)));
+        HIPCHK(ctx, hipMalloc(&p.pid, cap * sizeof(uint32_t)));
+        p.stride = (uint32_t)cap;
+    }
+    HIPCHK(ctx, hipMalloc(&ctx->d_L, 3 * cap * sizeof(float)));
+    ctx->pb_cap = cap;
+    return MIRT_OK;
+}
+
+struct Capture {
+    uint32_t depth_lo, depth_hi;
+    float* o;
+    float* d;
+    int* aux;
+    size_t capacity, count;
+};
+
+static hipEvent_t get_event(MirtContext* ctx, size_t k) {
+    while (ctx->events.size() <= k) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        ctx->events.push_back(ev);
+    }
+    return ctx->events[k];
+}
+
+// One wavefront of `S` samples per pixel starting at global sample index s0.
+static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRenderParams* prm,
+                         uint32_t s0, uint32_t S, float* rgb_sum, Capture* cap, uint64_t* n_rays,
+                         size_t* ev_used) {
+    const uint32_t wh = (uint32_t)cam.width * (uint32_t)cam.height;
+    const uint32_t P = wh * S;
+    hipStream_t st = ctx->stream;
+    const int B = 256;
+    PathBuf* cur = &ctx->pb[0];
+    PathBuf* nxt = &ctx->pb[1];
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_L, 0, 3 * ctx->pb_cap * sizeof(float), st));
+    hipLaunchKernelGGL(k_generate, dim3((P + B - 1) / B), dim3(B), 0, st, cam, P, s0, prm->seed, cur->o,
+                       cur->d, cur->stride, *cur, 1);
+    HIPCHK(ctx, hipGetLastError());
+    auto timed_intersect = [&](int mode, PathBuf* pb, uint32_t n) -> int {
+        hipEvent_t e0 = get_event(ctx, *ev_used), e1 = get_event(ctx, *ev_used + 1);
+        if (!e0 || !e1) return fail(ctx, MIRT_E_HIP, "hipEventCreate failed");
+        *ev_used += 2;
+        HIPCHK(ctx, hipEventRecord(e0, st));
+        int rc = launch_intersect<false, true>(ctx, st, mode, pb->o, pb->d, pb->ids, nullptr, n, pb->stride,
+                                               pb->t, pb->slot);
+        if (rc != MIRT_OK) return rc;
+        HIPCHK(ctx, hipEventRecord(e1, st));
+        return MIRT_OK;
+    };
+    int rc = timed_intersect(MIRT_MODE_UNCONDITIONAL, cur, P);  // Camera.cpp:27-33: no predicate
+    if (rc != MIRT_OK) return rc;
+    *n_rays += P;
+    uint32_t n = P;
+    for (uint32_t depth = 0; depth <= prm->max_depth && n > 0; depth++) {
+        uint32_t* cnt = ctx->d_cnt + (depth & 1);
+        HIPCHK(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_shade, dim3((n + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, nullptr, n,
+                           *nxt, cnt, ctx->d_L, (uint32_t)ctx->pb_cap, depth, prm->max_depth);
+        HIPCHK(ctx, hipGetLastError());
+        if (depth == prm->max_depth) break;  // nothing survives the depth cap (MCRenderer.cpp:187-191)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        n = ctx->h_cnt[0];
+        if (n == 0) break;
+        if (n > P) return fail(ctx, MIRT_E_HIP, "wavefront: live-path counter corrupted");
+        std::swap(cur, nxt);
+        if (cap && depth + 1 >= cap->depth_lo && depth + 1 <= cap->depth_hi && cap->count < cap->capacity) {
+            size_t m = std::min((size_t)n, cap->capacity - cap->count);
+            for (int c = 0; c < 3; c++) {
+                HIPCHK(ctx, hipMemcpyAsync(cap->o + c * cap->capacity + cap->count, cur->o + (size_t)c * cur->stride,
+                                           m * sizeof(float), hipMemcpyDeviceToDevice, st));
+                HIPCHK(ctx, hipMemcpyAsync(cap->d + c * cap->capacity + cap->count, cur->d + (size_t)c * cur->stride,
+                                           m * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+            HIPCHK(ctx, hipMemcpyAsync(cap->aux + cap->count, cur->ids, m * sizeof(int), hipMemcpyDeviceToDevice, st));
+            cap->count += m;
+        }
+        rc = timed_intersect(MIRT_MODE_NO_SELF, cur, n);  // MCRenderer.cpp:193-197
+        if (rc != MIRT_OK) return rc;
+        *n_rays += n;
+    }
+    if (rgb_sum) {
+        hipLaunchKernelGGL(k_accumulate, dim3((wh + B - 1) / B), dim3(B), 0, st, ctx->d_L,
+                           (uint32_t)ctx->pb_cap, wh, S, rgb_sum);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return MIRT_OK;
+}
+
+static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* rgb_sum_dev, Capture* cap,
+                         MirtRenderStats* stats) {
+    if (!ctx) return MIRT_E_INVALID;
+    if (!ctx->has_scene) return fail(ctx, MIRT_E_NO_SCENE, "render: no scene uploaded");
+    if (!prm) return fail(ctx, MIRT_E_INVALID, "render: params is NULL");
+    if (ctx->has_unsupported)
+        return fail(ctx, MIRT_E_INVALID,
+                    "render: the scene holds a homogeneous-medium (VPM) object; the shade kernel does "
+                    "not scatter in media yet");
+    DevCamera cam;
+    int rc = make_camera(ctx, &prm->camera, &cam);
+    if (rc != MIRT_OK) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t wh = (uint64_t)cam.width * cam.height;
+    uint32_t S = prm->spp_per_launch;
+    if (S == 0) S = (uint32_t)std::max<uint64_t>(1, (1ull << 22) / wh);  // ~4 Mi paths in flight
+    S = std::min<uint32_t>(S, std::max<uint32_t>(prm->spp_count, 1));
+    if (wh * S > (1ull << 30)) return fail(ctx, MIRT_E_LIMIT, "render: more than 2^30 paths per wavefront");
+    rc = ensure_paths(ctx, (size_t)(wh * S));
+    if (rc != MIRT_OK) return rc;
+    hipEvent_t t0 = get_event(ctx, 0), t1 = get_event(ctx, 1);
+    if (!t0 || !t1) return fail(ctx, MIRT_E_HIP, "hipEventCreate failed");
+    size_t ev_used = 2;
+    uint64_t n_rays = 0;
+    HIPCHK(ctx, hipEventRecord(t0, ctx->stream));
+    for (uint32_t done = 0; done < prm->spp_count; done += S) {
+        uint32_t s = std::min(S, prm->spp_count - done);
+        rc = run_wavefront(ctx, cam, prm, prm->spp_begin + done, s, rgb_sum_dev, cap, &n_rays, &ev_used);
+        if (rc != MIRT_OK) return rc;
+        if (ev_used > 4096) {  // fold the event pool so long renders do not grow it without bound
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (stats) {
+                for (size_t k = 2; k + 1 < ev_used; k += 2) {
+                    float ms = 0;
+                    hipEventElapsedTime(&ms, ctx->events[k], ctx->events[k + 1]);
+                    stats->intersect_ms += ms;
+                }
+            }
+            ev_used = 2;
+        }
+    }
+    HIPCHK(ctx, hipEventRecord(t1, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, t0, t1);
+        stats->gpu_ms = ms;
+        for (size_t k = 2; k + 1 < ev_used; k += 2) {
+            float m2 = 0;
+            hipEventElapsedTime(&m2, ctx->events[k], ctx->events[k + 1]);
+            stats->intersect_ms += m2;
+        }
+        stats->n_rays = n_rays;
+        stats->n_samples = wh * prm->spp_count;
+    }
+    return MIRT_OK;
+}
+
+extern "C" {
+
+int mirt_generate_rays_dev(MirtContext* ctx, const MirtCamera* camera, uint32_t spp_begin,
+                           uint32_t spp_count, uint32_t seed, float* origins, float* directions) {
+    if (!ctx) return MIRT_E_INVALID;
+    if (!origins || !directions) return fail(ctx, MIRT_E_INVALID, "generate_rays: NULL buffer");
+    DevCamera cam;
+    int rc = make_camera(ctx, camera, &cam);
+    if (rc != MIRT_OK) return rc;
+    uint64_t n = (uint64_t)cam.width * cam.height * spp_count;
+    if (n == 0) return MIRT_OK;
+    if (n > 0x7FFFFFFFull) return fail(ctx, MIRT_E_LIMIT, "generate_rays: more than 2^31-1 rays");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PathBuf none{};
+    hipLaunchKernelGGL(k_generate, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, cam,
+                       (uint32_t)n, spp_begin, seed, origins, directions, (uint32_t)n, none, 0);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MIRT_OK;
+}
+
+int mirt_render_pt_dev(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
+                       MirtRenderStats* stats) {
+    if (stats) *stats = MirtRenderStats{};
+    if (ctx && !rgb_sum) return fail(ctx, MIRT_E_INVALID, "render: rgb_sum is NULL");
+    return render_common(ctx, params, rgb_sum, nullptr, stats);
+}
+
+int mirt_render_pt(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
+                   MirtRenderStats* stats) {
+    if (stats) *stats = MirtRenderStats{};
+    if (!ctx) return MIRT_E_INVALID;
+    if (!rgb_sum || !params) return fail(ctx, MIRT_E_INVALID, "render: NULL argument");
+    if (!ctx->has_scene) return fail(ctx, MIRT_E_NO_SCENE, "render: no scene uploaded");
+    if (params->camera.width <= 0 || params->camera.height <= 0)
+        return fail(ctx, MIRT_E_INVALID, "camera: width/height must be positive");
+    size_t bytes = (size_t)params->camera.width * params->camera.height * 3 * sizeof(float);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    float* d_rgb = nullptr;
+    HIPCHK(ctx, hipMalloc(&d_rgb, bytes));
+    hipError_t e = hipMemsetAsync(d_rgb, 0, bytes, ctx->stream);
+    int rc = e == hipSuccess ? render_common(ctx, params, d_rgb, nullptr, stats)
+                             : fail(ctx, MIRT_E_HIP, hipGetErrorString(e));
+    if (rc == MIRT_OK) {
+        e = hipMemcpy(rgb_sum, d_rgb, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, MIRT_E_HIP, hipGetErrorString(e));
+    }
+    hipFree(d_rgb);
+    return rc;
+}
+
+int mirt_capture_rays_dev(MirtContext* ctx, const MirtRenderParams* params, uint32_t depth_lo,
+                          uint32_t depth_hi, float* origins, float* directions, int32_t* aux,
+                          size_t capacity, size_t* n_captured) {
+    if (!ctx) return MIRT_E_INVALID;
+    if (!origins || !directions || !aux || !n_captured || capacity == 0)
+        return fail(ctx, MIRT_E_INVALID, "capture_rays: NULL buffer or zero capacity");
+    if (depth_lo < 1 || depth_hi < depth_lo)
+        return fail(ctx, MIRT_E_INVALID, "capture_rays: need 1 <= depth_lo <= depth_hi");
+    Capture cap{depth_lo, depth_hi, origins, directions, aux, capacity, 0};
+    int rc = render_common(ctx, params, nullptr, &cap, nullptr);
+    *n_captured = cap.count;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// mirt_dev.h — device-side data layout and exact-arithmetic geometry helpers (gfx950 only).
+//
+// Everything that decides WHICH triangle a ray hits is evaluated with the same operations, in the
+// same order and with the same roundings as the reference CPU path (KDTree.cpp:34-52, 267-293;
+// NoSelfIntersectionCondition.cpp:12-27; SimpleShape.cpp:300-339): fp32, one rounding per
+// multiply and add (no contraction to FMA), correctly rounded division and square root (hipcc's
+// default for HIP). This file is compiled with -ffp-contract=off and repeats the request below.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mirt.h"
+
+#pragma clang fp contract(off)
+
+namespace mirt {
+
+// ---- HBM layout ------------------------------------------------------------------------------
+// node record, 32 B, pre-order (left child = i+1):
+//   lo = (min.x, min.y, min.z, bits(c0))   hi = (max.x, max.y, max.z, bits(c1))
+//   inner: c0 = right child index (> 0), c1 = 0        leaf: c0 = ~leaf_begin (< 0), c1 = leaf_end
+struct NodeRec {
+    float4 lo, hi;
+};
+// triangle record in SLOT (leaf) order, 48 B: positions + the unit plane normal the reference
+// recomputes per test (KDTree.cpp:283-284), precomputed on the host with identical arithmetic.
+//   a = (v0, n.x)  b = (v1, n.y)  c = (v2, n.z)
+struct TriRec {
+    float4 a, b, c;
+};
+// per-slot shading data, 48 B, touched only for candidate hits that would win (predicate) and in
+// the shade kernel: corner normals (normal-matrix transformed, not normalised).
+struct VnRec {
+    float4 n0, n1, n2;  // .w of n0 = bits(object id), n1.w = bits(global tid), n2.w unused
+};
+
+struct DevObject {
+    int type, has_vn, volumetric, pad;
+    float color[3];
+    float coeff;
+    float ior;
+    float decay[3];
+};
+
+struct DevScene {
+    const NodeRec* nodes;
+    const TriRec* tris;
+    const VnRec* vns;
+    const DevObject* objects;
+    int n_nodes, n_tris, n_objects, depth;
+};
+
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ f3 neg(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+// nvVector.h:501-507 order: ((x*x) + y*y) + z*z, each product and sum rounded
+__device__ __forceinline__ float dot3(f3 a, f3 b) {
+    float r = a.x * b.x;
+    r = r + a.y * b.y;
+    r = r + a.z * b.z;
+    return r;
+}
+__device__ __forceinline__ f3 cross3(f3 l, f3 r) {
+    return f3{l.y * r.z - l.z * r.y, l.z * r.x - l.x * r.z, l.x * r.y - l.y * r.x};
+}
+__device__ __forceinline__ float len3(f3 a) { return sqrtf(dot3(a, a)); }
+// nvVector.h:376-380, 522-526: zero vectors (and NaN lengths) are left alone
+__device__ __forceinline__ f3 normalize3(f3 a) {
+    float r = len3(a);
+    if (r > 0.f) return f3{a.x / r, a.y / r, a.z / r};
+    return a;
+}
+__device__ __forceinline__ f3 div3(f3 a, float d) {
+    if (d == 0.f) return a;
+    return f3{a.x / d, a.y / d, a.z / d};
+}
+__device__ __forceinline__ float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// ---- node box test ---------------------------------------------------------------------------
+// `hit` is exactly KDTree::Node::BoundingBox::intersect(ray) >= 0 (KDTree.cpp:34-52); `lb` is a
+// lower bound of the parametric distance of any point of the box (slab entry, from the same six
+// quotients), used only to skip subtrees that cannot beat the current closest hit.
+struct BoxHit {
+    bool hit;
+    float lb;
+};
+__device__ __forceinline__ BoxHit box_test(const float4 lo, const float4 hi, f3 o, f3 d) {
+    bool hit = false;
+    float lb = 0.f;
+    // axis x: planes lo.x / hi.x, other axes y, z
+    if (d.x != 0.f) {
+        float t0 = (lo.x - o.x) / d.x;
+        float t1 = (hi.x - o.x) / d.x;
+        float py = o.y + t0 * d.y, pz = o.z + t0 * d.z;
+        hit |= (t0 >= 0.f) & (lo.y <= py) & (hi.y >= py) & (lo.z <= pz) & (hi.z >= pz);
+        py = o.y + t1 * d.y;
+        pz = o.z + t1 * d.z;
+        hit |= (t1 >= 0.f) & (lo.y <= py) & (hi.y >= py) & (lo.z <= pz) & (hi.z >= pz);
+        float nr = t0 < t1 ? t0 : t1;
+        lb = nr > lb ? nr : lb;
+    }
+    if (d.y != 0.f) {
+        float t0 = (lo.y - o.y) / d.y;
+        float t1 = (hi.y - o.y) / d.y;
+        float pz = o.z + t0 * d.z, px = o.x + t0 * d.x;
+        hit |= (t0 >= 0.f) & (lo.z <= pz) & (hi.z >= pz) & (lo.x <= px) & (hi.x >= px);
+        pz = o.z + t1 * d.z;
+        px = o.x + t1 * d.x;
+        hit |= (t1 >= 0.f) & (lo.z <= pz) & (hi.z >= pz) & (lo.x <= px) & (hi.x >= px);
+        float nr = t0 < t1 ? t0 : t1;
+        lb = nr > lb ? nr : lb;
+    }
+    if (d.z != 0.f) {
+        float t0 = (lo.z - o.z) / d.z;
+        float t1 = (hi.z - o.z) / d.z;
+        float px = o.x + t0 * d.x, py = o.y + t0 * d.y;
+        hit |= (t0 >= 0.f) & (lo.x <= px) & (hi.x >= px) & (lo.y <= py) & (hi.y >= py);
+        px = o.x + t1 * d.x;
+        py = o.y + t1 * d.y;
+        hit |= (t1 >= 0.f) & (lo.x <= px) & (hi.x >= px) & (lo.y <= py) & (hi.y >= py);
+        float nr = t0 < t1 ? t0 : t1;
+        lb = nr > lb ? nr : lb;
+    }
+    return BoxHit{hit, lb};
+}
+
+// a subtree whose box starts beyond the closest accepted hit cannot change the result; the slack
+// covers the rounding of t (plane equation) against lb (slab quotients).
+__device__ __forceinline__ bool prune(float lb, bool have, float best) {
+    return have && lb > best * 1.0001f + 1e-5f;
+}
+
+// ---- triangle test (KDTree.cpp:267-289), returns dist or -1 -------------------------------------
+__device__ __forceinline__ float tri_test(const TriRec& T, f3 o, f3 d) {
+    f3 v0 = mk3(T.a.x, T.a.y, T.a.z), v1 = mk3(T.b.x, T.b.y, T.b.z), v2 = mk3(T.c.x, T.c.y, T.c.z);
+    f3 n = mk3(T.a.w, T.b.w, T.c.w);
+    f3 l0 = v1 - v0, l1 = v2 - v1, l2 = v0 - v2;
+    f3 r0 = v0 - o, r1 = v1 - o, r2 = v2 - o;
+    float s0 = dot3(d, cross3(l0, r0));
+    float s1 = dot3(d, cross3(l1, r1));
+    float s2 = dot3(d, cross3(l2, r2));
+    bool all_pos = (s0 >= 0.f) & (s1 >= 0.f) & (s2 >= 0.f);
+    bool all_neg = (s0 <= 0.f) & (s1 <= 0.f) & (s2 <= 0.f);
+    float orthoDist = dot3(n, r2);
+    float dd = dot3(n, d);
+    float q = orthoDist / dd;
+    if (dd == 0.f || q < 0.f || !(all_pos | all_neg)) return -1.f;
+    return q;
+}
+
+// ---- shading normal (SimpleShape.cpp:300-339 through SceneObject.cpp:250-254) ------------------
+__device__ __forceinline__ f3 world_normal(const TriRec& T, const VnRec& V, bool has_vn, f3 pos) {
+    f3 v0 = mk3(T.a.x, T.a.y, T.a.z), v1 = mk3(T.b.x, T.b.y, T.b.z), v2 = mk3(T.c.x, T.c.y, T.c.z);
+    f3 b1 = v1 - v0, b2 = v2 - v0;
+    if (!has_vn) return normalize3(cross3(b1, b2));
+    f3 v = pos - v0;
+    float d12 = dot3(b1, b2);
+    float l1 = len3(b1), l2 = len3(b2);
+    float vb1 = dot3(v, b1), vb2 = dot3(v, b2);
+    float u2 = (vb1 * d12 - vb2 * l1 * l1) / (d12 * d12 - l1 * l1 * l2 * l2);
+    float u1 = (vb1 - u2 * d12) / (l1 * l1);
+    f3 n0 = mk3(V.n0.x, V.n0.y, V.n0.z), n1 = mk3(V.n1.x, V.n1.y, V.n1.z),
+       n2 = mk3(V.n2.x, V.n2.y, V.n2.z);
+    f3 nn = ((1.f - u1 - u2) * n0 + u1 * n1) + u2 * n2;
+    return normalize3(nn);
+}
+
+// NoSelfIntersectionCondition.cpp:12-27; ids are object ids, -1 = NULL
+__device__ __forceinline__ bool legal_noself(float dn, int hitObj, int contact, int inside) {
+    bool in = dn <= 0.f, out = dn >= 0.f;
+    if (inside == contact) return !(in && contact == hitObj);
+    return !(out && inside != hitObj);
+}
+
+__device__ __forceinline__ int unpack_contact(int aux) { return (int)((uint32_t)aux & 0xFFFFu) - 1; }
+__device__ __forceinline__ int unpack_inside(int aux) {
+    return (int)(((uint32_t)aux >> 16) & 0xFFFFu) - 1;
+}
+
+}  // namespace mirt

@@ -1,0 +1,307 @@
+// config.cpp — xmlHelper, ConfigManager (XML -> Scene/Camera/integrator), MCRenderer, PathTracerHIP,
+// Renderer. Follows ConfigManager.cpp:25-433, xmlHelper.cpp:4-23, MCRenderer.cpp:500-518,
+// Renderer.cpp:46-91 for the parts on the path-tracing path; every other integrator type is refused
+// with a clear error instead of being silently ignored.
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+#include "host.h"
+
+namespace mirt_host {
+
+// xmlHelper.cpp:4-16: "[r0][r1][r2][r3]", row-major text
+matrix4 readMatrix(const char* value) {
+    float v[16];
+    int got = sscanf(value, "[%f, %f, %f, %f][%f, %f, %f, %f][%f, %f, %f, %f][%f, %f, %f, %f]", v, v + 1,
+                     v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9, v + 10, v + 11, v + 12, v + 13,
+                     v + 14, v + 15);
+    if (got != 16) throw std::runtime_error(std::string("readMatrix: cannot parse '") + value + "'");
+    matrix4 m;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) m(r, c) = v[4 * r + c];
+    return m;
+}
+
+// xmlHelper.cpp:18-23: "(x, y, z)"
+vec3f readVec(const char* value) {
+    vec3f v;
+    if (sscanf(value, " (%f, %f, %f)", &v.x, &v.y, &v.z) != 3)
+        throw std::runtime_error(std::string("readVec: cannot parse '") + value + "'");
+    return v;
+}
+
+static std::string folderOf(const std::string& path) {
+    size_t p = path.find_last_of("/\\");
+    return p == std::string::npos ? std::string(".") : path.substr(0, p);
+}
+
+static bool fileExists(const std::string& p) { return access(p.c_str(), F_OK) == 0; }
+
+std::string ConfigManager::resolve(const std::string& path) const {
+    if (fileExists(path)) return path;  // ConfigManager.cpp:196-199, 238-241, 391-392
+    return rootFolder + "/" + path;
+}
+
+XmlNode* ConfigManager::findNode(const std::string& filePath, const std::string& nodeTag,
+                                 const std::string& nodeName) {
+    if (filePath.empty()) return nullptr;
+    std::string full = resolve(filePath);
+    auto it = path_doc.find(full);
+    if (it == path_doc.end()) {
+        std::ifstream in(full.c_str(), std::ios::binary);
+        if (!in) throw std::runtime_error("ConfigManager: cannot open " + full);
+        std::stringstream ss;
+        ss << in.rdbuf();
+        std::unique_ptr<XmlDocument> doc(new XmlDocument);
+        doc->parse(ss.str());
+        it = path_doc.emplace(full, std::move(doc)).first;
+    }
+    return findNode(it->second.get(), nodeTag, nodeName);
+}
+
+// ConfigManager.cpp:415-425: first node of that tag with no Name, or any node when no name is asked
+XmlNode* ConfigManager::findNode(XmlNode* root, const std::string& nodeTag, const std::string& nodeName) {
+    for (XmlNode* n = root->first_node(nodeTag.c_str()); n; n = n->next_sibling(nodeTag.c_str())) {
+        const std::string* nm = n->first_attribute("Name");
+        if (!nm || nodeName.empty()) return n;
+        if (*nm == nodeName) return n;
+    }
+    return nullptr;
+}
+
+std::pair<std::string, std::string> ConfigManager::getPathAndName(XmlNode* node) {
+    std::pair<std::string, std::string> pn;
+    pn.first = node->first_node("path") ? node->first_node("path")->value() : currentPath;
+    pn.second = node->first_node("name") ? node->first_node("name")->value() : "";
+    return pn;
+}
+
+static void setColor(float dst[3], const vec3f& v) {
+    dst[0] = v.x;
+    dst[1] = v.y;
+    dst[2] = v.z;
+}
+
+// ConfigManager.cpp:25-164 with the defaults of the Scene*Object constructors
+SceneObject* ConfigManager::generateSceneObject(XmlNode* nodeObj, XmlNode* nodeMat) {
+    XmlNode* typeNode = nodeMat->first_node("type");
+    if (!typeNode) throw std::runtime_error("ConfigManager: <Material> without <type>");
+    const std::string type = typeNode->value();
+    std::unique_ptr<SceneObject> obj(new SceneObject(&renderer->scene));
+    MirtObject& m = obj->material;
+    if (nodeObj->first_node("transform")) obj->setTransform(readMatrix(nodeObj->first_node("transform")->value()));
+    if (nodeMat->first_node("BumpTexture") || nodeMat->first_node("Texture") ||
+        nodeMat->first_node("ColorTexture") || nodeMat->first_node("CoeffTexture"))
+        throw std::runtime_error("ConfigManager: image / bump textures are outside this build (constant colours only)");
+    if (type == "Diffuse") {
+        m.type = MIRT_OBJ_DIFFUSE;
+        if (nodeMat->first_node("color")) setColor(m.color, readVec(nodeMat->first_node("color")->value()));
+    } else if (type == "Glossy") {
+        m.type = MIRT_OBJ_GLOSSY;
+        if (nodeMat->first_node("color")) setColor(m.color, readVec(nodeMat->first_node("color")->value()));
+        if (nodeMat->first_node("coeff")) m.coeff = (float)atof(nodeMat->first_node("coeff")->value());
+    } else if (type == "Emissive") {
+        m.type = MIRT_OBJ_EMISSIVE;
+        if (!nodeMat->first_node("color")) throw std::runtime_error("ConfigManager: Emissive material needs <color>");
+        setColor(m.color, readVec(nodeMat->first_node("color")->value()));
+    } else if (type == "Refractive") {  // SceneRefractiveObject.h:12-20
+        m.type = MIRT_OBJ_REFRACTIVE;
+        m.ior = 1.5f;
+        if (nodeMat->first_node("coeff")) m.ior = (float)atof(nodeMat->first_node("coeff")->value());
+        if (nodeMat->first_node("surfColor")) setColor(m.color, readVec(nodeMat->first_node("surfColor")->value()));
+        if (nodeMat->first_node("decayColor")) setColor(m.decay, readVec(nodeMat->first_node("decayColor")->value()));
+    } else if (type == "Reflective") {  // SceneReflectiveObject.h:9-17: refrCoeff -1 = mirror
+        m.type = MIRT_OBJ_REFRACTIVE;
+        m.ior = -1.f;
+        if (nodeMat->first_node("color")) setColor(m.color, readVec(nodeMat->first_node("color")->value()));
+    } else if (type == "VPM") {
+        m.type = MIRT_OBJ_VPM;
+        m.volumetric = 1;
+        if (!nodeMat->first_node("sigma_s") || !nodeMat->first_node("sigma_a") ||
+            !nodeMat->first_node("inrate") || !nodeMat->first_node("g"))
+            throw std::runtime_error("ConfigManager: VPM material needs sigma_s, sigma_a, inrate, g");
+        setColor(m.sigma_s, readVec(nodeMat->first_node("sigma_s")->value()));
+        setColor(m.sigma_a, readVec(nodeMat->first_node("sigma_a")->value()));
+        m.ior = (float)atof(nodeMat->first_node("inrate")->value());
+        m.g = (float)atof(nodeMat->first_node("g")->value());
+    } else {
+        throw std::runtime_error("ConfigManager: material type '" + type + "' is outside this build");
+    }
+    return obj.release();
+}
+
+// ConfigManager::load (ConfigManager.cpp:166-384)
+void ConfigManager::load(const std::string& configFilePath) {
+    path_doc.clear();
+    renderer->scene.clear();
+    rootFolder = folderOf(configFilePath);
+    XmlNode* nodeConfig = findNode(configFilePath, "Config", "");
+    if (!nodeConfig) throw std::runtime_error("ConfigManager: no <Config> in " + configFilePath);
+    if (nodeConfig->first_node("useGPU"))  // ConfigManager.cpp:176-181; the HIP path is always on
+        renderer->scene.setGPU(true);
+
+    XmlNode* nodeSceneConfig = nodeConfig->first_node("Scene");
+    if (!nodeSceneConfig) throw std::runtime_error("ConfigManager: <Config> without <Scene>");
+    std::pair<std::string, std::string> pn = getPathAndName(nodeSceneConfig);
+    XmlNode* nodeScene = findNode(pn.first, "Scene", pn.second);
+    if (!nodeScene) nodeScene = findNode(configFilePath, "Scene", pn.second);
+    if (!nodeScene) throw std::runtime_error("ConfigManager: scene '" + pn.second + "' not found");
+    currentPath = pn.first;
+
+    if (nodeScene->first_node("GroupObject"))
+        throw std::runtime_error("ConfigManager: <GroupObject> is outside this build");
+
+    for (XmlNode* nodeObj = nodeScene->first_node("Object"); nodeObj; nodeObj = nodeObj->next_sibling("Object")) {
+        XmlNode* matRef = nodeObj->first_node("Material");
+        if (!matRef) throw std::runtime_error("ConfigManager: <Object> without <Material>");
+        pn = getPathAndName(matRef);
+        // lookup order: named file -> scene-local -> inline (ConfigManager.cpp:230-235)
+        XmlNode* nodeMat = findNode(pn.first, "Material", pn.second);
+        if (!nodeMat && matRef->first_node("name")) nodeMat = findNode(nodeScene, "Material", pn.second);
+        if (!nodeMat) nodeMat = matRef;
+        if (!nodeObj->first_node("filePath")) throw std::runtime_error("ConfigManager: <Object> without <filePath>");
+        std::string path = resolve(nodeObj->first_node("filePath")->value());
+        SceneObject* obj = generateSceneObject(nodeObj, nodeMat);
+        try {
+            obj->loadShape(path, true);  // ConfigManager.cpp:245
+        } catch (...) {
+            delete obj;
+            throw;
+        }
+        renderer->scene.objects.push_back(obj);
+    }
+
+    XmlNode* camName = nodeSceneConfig->first_node("camera");
+    XmlNode* nodeCam = findNode(nodeScene, "Camera", camName ? camName->value() : "");
+    if (!nodeCam) throw std::runtime_error("ConfigManager: camera not found");
+    Camera& cam = renderer->camera;
+    auto need = [&](const char* tag) {
+        XmlNode* n = nodeCam->first_node(tag);
+        if (!n) throw std::runtime_error(std::string("ConfigManager: <Camera> without <") + tag + ">");
+        return n->value();
+    };
+    cam.width = atoi(need("width"));
+    cam.height = atoi(need("height"));
+    cam.sightDist = (unsigned)atoi(need("sightDist"));
+    cam.focus = readVec(need("focus"));
+    cam.position = readVec(need("position"));
+    cam.up = readVec(need("up"));
+
+    renderer->scene.buildKDTree(renderer->uploadOnLoad);
+
+    delete renderer->mcRenderer;
+    renderer->mcRenderer = nullptr;
+    // <renderer>name</renderer> or <Renderer><type>name</type>...</Renderer> (ConfigManager.cpp:278-378)
+    std::string typeName;
+    XmlNode* opts = nodeConfig;
+    if (nodeConfig->first_node("renderer")) typeName = nodeConfig->first_node("renderer")->value();
+    if (XmlNode* r = nodeConfig->first_node("Renderer")) {
+        if (!r->first_node("type")) throw std::runtime_error("ConfigManager: <Renderer> without <type>");
+        typeName = r->first_node("type")->value();
+        opts = r;
+    }
+    if (typeName == "PathTracer" || typeName == "PT" || typeName == "PTHIP") {
+        PathTracerHIP* pt = new PathTracerHIP(renderer);
+        if (opts->first_node("spp")) pt->spp = (unsigned)atoi(opts->first_node("spp")->value());
+        if (opts->first_node("seed")) pt->seed = (unsigned)atoi(opts->first_node("seed")->value());
+        renderer->mcRenderer = pt;
+    } else {
+        throw std::runtime_error("ConfigManager: renderer type '" + typeName +
+                                 "' is outside this build (PathTracer / PT / PTHIP only)");
+    }
+    if (opts->first_node("maxDepth")) renderer->mcRenderer->setMaxDepth(atoi(opts->first_node("maxDepth")->value()));
+    if (nodeConfig->first_node("savePath")) renderer->mcRenderer->setSavePath(nodeConfig->first_node("savePath")->value());
+}
+
+// ---- MCRenderer -------------------------------------------------------------------------------------
+std::vector<vec3f> MCRenderer::renderPixels(const Camera& camera) {
+    return std::vector<vec3f>((size_t)camera.width * camera.height, vec3f(0, 0, 0));  // MCRenderer.h:114-117
+}
+
+// MCRenderer.cpp:500-518: "PF\nW H\n-1.000000\n", rows bottom-to-top, channels R,G,B, little-endian
+void MCRenderer::saveImagePFM(const std::string& fileName, const std::vector<vec3f>& pixels, int w, int h) {
+    FILE* f = fopen(fileName.c_str(), "wb");
+    if (!f) throw std::runtime_error("saveImagePFM: cannot open " + fileName);
+    fprintf(f, "PF\n%d %d\n-1.000000\n", w, h);
+    for (int j = h - 1; j >= 0; j--)
+        for (int i = 0; i < w; i++) {
+            const vec3f& p = pixels[(size_t)j * w + i];
+            float rgb[3] = {p.x, p.y, p.z};
+            fwrite(rgb, sizeof(float), 3, f);
+        }
+    fclose(f);
+}
+
+bool MCRenderer::loadImagePFM(const std::string& fileName, std::vector<vec3f>& pixels, int& w, int& h) {
+    FILE* f = fopen(fileName.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0, 0, 0};
+    float scale = 0;
+    if (fscanf(f, "%2s %d %d %f", magic, &w, &h, &scale) != 4 || strcmp(magic, "PF") != 0 || w <= 0 || h <= 0) {
+        fclose(f);
+        return false;
+    }
+    fgetc(f);  // the single whitespace after the scale
+    pixels.assign((size_t)w * h, vec3f());
+    bool ok = true;
+    for (int j = h - 1; j >= 0 && ok; j--)
+        for (int i = 0; i < w; i++) {
+            float rgb[3];
+            if (fread(rgb, sizeof(float), 3, f) != 3) {
+                ok = false;
+                break;
+            }
+            pixels[(size_t)j * w + i] = vec3f(rgb[0], rgb[1], rgb[2]);
+        }
+    fclose(f);
+    return ok;
+}
+
+// ---- PathTracerHIP ----------------------------------------------------------------------------------
+// PathTracer::renderPixels (PathTracer.cpp:4-58): spp passes of one sample per pixel, running mean.
+// Here the passes run on the device; the sums come back once and are divided by spp.
+std::vector<vec3f> PathTracerHIP::renderPixels(const Camera& camera) {
+    MirtContext* ctx = IntersectionHIP::context();
+    if (!ctx) throw std::runtime_error("PathTracerHIP::renderPixels: the scene was not loaded to the device");
+    MirtRenderParams p;
+    memset(&p, 0, sizeof p);
+    p.camera = camera.toMirt();
+    p.spp_begin = 0;
+    p.spp_count = spp;
+    p.max_depth = maxDepth;
+    p.seed = seed;
+    p.spp_per_launch = sppPerLaunch;
+    const size_t npix = (size_t)camera.width * camera.height;
+    std::vector<float> sum(3 * npix);
+    if (mirt_render_pt(ctx, &p, sum.data(), &lastStats) != MIRT_OK)
+        throw std::runtime_error(std::string("PathTracerHIP::renderPixels: ") + mirt_last_error(ctx));
+    std::vector<vec3f> pixelColors(npix);
+    const float inv = spp ? 1.f / float(spp) : 0.f;
+    for (size_t i = 0; i < npix; i++)
+        pixelColors[i] = vec3f(sum[3 * i] * inv, sum[3 * i + 1] * inv, sum[3 * i + 2] * inv);
+    if (!savePath.empty()) saveImagePFM(savePath, pixelColors, camera.width, camera.height);
+    return pixelColors;
+}
+
+// ---- Renderer ---------------------------------------------------------------------------------------
+Renderer::Renderer() { configManager = new ConfigManager(this); }
+
+Renderer::~Renderer() {
+    delete mcRenderer;
+    delete configManager;
+}
+
+void Renderer::loadConfig(const std::string& configFilePath) { configManager->load(configFilePath); }
+
+std::vector<vec3f> Renderer::render() {
+    if (!mcRenderer) throw std::runtime_error("Renderer::render: no integrator configured");
+    return mcRenderer->renderPixels(camera);  // Renderer.cpp:46-50
+}
+
+}  // namespace mirt_host

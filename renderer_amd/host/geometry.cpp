@@ -1,0 +1,261 @@
+// geometry.cpp — SimpleShape (.obj loading, unitize, world normals), SceneObject, KDTree build.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+#include "host.h"
+
+namespace mirt_host {
+
+// ---- SimpleShape ------------------------------------------------------------------------------------
+void SimpleShape::getBoundingBox(vec3f& lo, vec3f& hi) const {
+    if (vertexList.empty()) return;
+    lo = hi = vertexList[0];
+    for (size_t i = 1; i < vertexList.size(); i++)
+        for (int c = 0; c < 3; c++) {
+            float v = vertexList[i][c];
+            lo[c] = v < lo[c] ? v : lo[c];
+            hi[c] = v > hi[c] ? v : hi[c];
+        }
+}
+
+// SimpleShape.cpp:257-272: recentre on the box centre, scale the longest extent to [-1, 1]
+void SimpleShape::unitize() {
+    if (vertexList.empty()) return;
+    vec3f lo, hi;
+    getBoundingBox(lo, hi);
+    vec3f center = (lo + hi) / 2;
+    vec3f delta = hi - lo;
+    float maxLen = delta.x > delta.y ? delta.x : delta.y;
+    maxLen = maxLen > delta.z ? maxLen : delta.z;
+    for (auto& v : vertexList) {
+        v = v - center;
+        v = v / (maxLen / 2);
+    }
+}
+
+// Face token forms a, a/b, a/b/c, a//c with 1-based indices (SimpleShape.cpp:116-139). Returns the
+// number of integers the "%d/%d/%d" pattern matched and, when that is 1, retries "%d//%d".
+static void parseFaceToken(const char* tok, unsigned& v, unsigned& t, unsigned& n, int& got3, int& got2) {
+    int a = 0, b = 0, c = 0;
+    got3 = sscanf(tok, "%d/%d/%d", &a, &b, &c);
+    got2 = 0;
+    if (got3 >= 1) v = (unsigned)a;
+    if (got3 >= 2) t = (unsigned)b;
+    if (got3 >= 3) n = (unsigned)c;
+    if (got3 == 1) {
+        int a2 = 0, c2 = 0;
+        got2 = sscanf(tok, "%d//%d", &a2, &c2);
+        if (got2 >= 1) v = (unsigned)a2;
+        if (got2 == 2) n = (unsigned)c2;
+    }
+}
+
+// SimpleShape.cpp:44-220 for ".obj" without group splitting. Rules kept: '#' lines are skipped; a
+// line counts only if it has at least 4 whitespace-separated tokens and only the first 4 are read
+// (faces must be triangles; "vt" needs 3 numbers); no material handling.
+void SimpleShape::loadShape(const std::string& fileName, bool normalize) {
+    vertexList.clear();
+    faceVertexIndexList.clear();
+    vertexNormalList.clear();
+    vertexTexCoordList.clear();
+    faceVertexNormalIndexList.clear();
+    faceVertexTexCoordIndexList.clear();
+    if (fileName.size() < 4 || fileName.substr(fileName.size() - 4) != ".obj")
+        throw std::runtime_error("loadShape: only .obj meshes are supported: " + fileName);
+    FILE* file = fopen(fileName.c_str(), "r");
+    if (!file) throw std::runtime_error("loadShape: cannot open " + fileName);
+    char line[1024], attrib[1024], parms[3][1024];
+    while (fgets(line, sizeof line, file)) {
+        if (line[0] == '#') continue;
+        int num = sscanf(line, "%1023s %1023s %1023s %1023s", attrib, parms[0], parms[1], parms[2]);
+        if (num != 4) continue;
+        if (strcmp("v", attrib) == 0 || strcmp("vn", attrib) == 0 || strcmp("vt", attrib) == 0) {
+            vec3f v;
+            sscanf(parms[0], "%f", &v.x);
+            sscanf(parms[1], "%f", &v.y);
+            sscanf(parms[2], "%f", &v.z);
+            if (attrib[1] == 0)
+                vertexList.push_back(v);
+            else if (attrib[1] == 'n')
+                vertexNormalList.push_back(v);
+            else
+                vertexTexCoordList.push_back(v);
+        } else if (strcmp("f", attrib) == 0) {
+            vec3ui tri{0, 0, 0}, vn{0, 0, 0}, vt{0, 0, 0};
+            int got3 = 0, got2 = 0;
+            for (int k = 0; k < 3; k++) parseFaceToken(parms[k], tri[k], vt[k], vn[k], got3, got2);
+            // the form of the LAST token decides what the face carries (SimpleShape.cpp:118-139)
+            bool has_n = got3 == 3 || (got3 == 1 && got2 == 2);
+            bool has_t = got3 >= 2;
+            for (int k = 0; k < 3; k++) {
+                tri[k] -= 1;
+                vn[k] -= 1;
+                vt[k] -= 1;
+            }
+            faceVertexIndexList.push_back(tri);
+            if (has_n) faceVertexNormalIndexList.push_back(vn);
+            if (has_t) faceVertexTexCoordIndexList.push_back(vt);
+        }
+    }
+    fclose(file);
+    for (auto& f : faceVertexIndexList)
+        for (int k = 0; k < 3; k++)
+            if (f[k] >= vertexList.size())
+                throw std::runtime_error("loadShape: face index out of range in " + fileName);
+    for (auto& f : faceVertexNormalIndexList)
+        for (int k = 0; k < 3; k++)
+            if (f[k] >= vertexNormalList.size())
+                throw std::runtime_error("loadShape: normal index out of range in " + fileName);
+    if (normalize) unitize();
+    getBoundingBox(minCoord, maxCoord);
+}
+
+bool SimpleShape::hasVertexNormals() const {
+    return !vertexNormalList.empty() && faceVertexNormalIndexList.size() == faceVertexIndexList.size();
+}
+
+bool SimpleShape::getWorldCornerNormals(unsigned fi, vec3f out[3]) const {
+    if (!hasVertexNormals()) return false;
+    matrix4 normalMat = transform.inverse().transposed();
+    for (int i = 0; i < 3; i++) out[i] = normalMat.apply(vertexNormalList[faceVertexNormalIndexList[fi][i]], 0.f);
+    return true;
+}
+
+// ---- SceneObject ------------------------------------------------------------------------------------
+SceneObject::SceneObject(Scene* s) : scene(s), objectIndex(-1) {
+    memset(&material, 0, sizeof material);
+    material.type = MIRT_OBJ_DIFFUSE;
+    material.ior = 1.f;
+    for (int c = 0; c < 3; c++) material.color[c] = material.decay[c] = 1.f;
+}
+
+float SceneObject::getRefrCoeff() const {
+    if ((material.type == MIRT_OBJ_REFRACTIVE && material.ior >= 0) || material.type == MIRT_OBJ_VPM)
+        return material.ior;
+    return 1.f;  // SceneObject.h:58
+}
+
+// ---- KDTree -----------------------------------------------------------------------------------------
+void KDTree::destroy() {
+    triangleList.clear();
+    vertexPositionList.clear();
+    nodeMin.clear();
+    nodeMax.clear();
+    nodeRight.clear();
+    nodeLeafBegin.clear();
+    nodeLeafEnd.clear();
+    slotTid.clear();
+    depth = 0;
+}
+
+vec3f KDTree::getDiagonal() const {
+    if (nodeMin.empty()) return vec3f();
+    return vec3f(nodeMax[0] - nodeMin[0], nodeMax[1] - nodeMin[1], nodeMax[2] - nodeMin[2]);
+}
+
+// One node of the median-split tree (KDTree::splitBest, KDTree.cpp:129-228), emitted in pre-order.
+// `order[begin,end)` holds the node's triangles in the reference's order (a stable partition keeps
+// it), so a leaf's slot range is simply [begin,end).
+void KDTree::buildNode(std::vector<unsigned>& order, size_t begin, size_t end, int level,
+                       std::vector<unsigned>& stamp, unsigned& stampGen, std::vector<unsigned>& uniq,
+                       std::vector<float>& coords) {
+    const size_t me = nodeRight.size();
+    nodeRight.push_back(-1);
+    nodeLeafBegin.push_back(-1);
+    nodeLeafEnd.push_back(-1);
+    if (level > depth) depth = level;
+    // tight bounds of the node's triangles (KDTree.cpp:139-153) + its distinct vertex ids
+    vec3f lo = vertexPositionList[triangleList[order[begin]].vertexIndices[0]], hi = lo;
+    stampGen++;
+    uniq.clear();
+    for (size_t i = begin; i < end; i++)
+        for (int k = 0; k < 3; k++) {
+            unsigned vi = triangleList[order[i]].vertexIndices[k];
+            const vec3f& p = vertexPositionList[vi];
+            for (int c = 0; c < 3; c++) {
+                lo[c] = p[c] < lo[c] ? p[c] : lo[c];
+                hi[c] = p[c] > hi[c] ? p[c] : hi[c];
+            }
+            if (stamp[vi] != stampGen) {
+                stamp[vi] = stampGen;
+                uniq.push_back(vi);
+            }
+        }
+    for (int c = 0; c < 3; c++) {
+        nodeMin.push_back(lo[c]);
+        nodeMax.push_back(hi[c]);
+    }
+    auto makeLeaf = [&]() {
+        nodeLeafBegin[me] = (int32_t)begin;
+        nodeLeafEnd[me] = (int32_t)end;
+    };
+    const size_t count = end - begin;
+    if (count <= 1) {  // maxLeafTriangleNum = 1 (KDTree.cpp:24)
+        makeLeaf();
+        return;
+    }
+    // per axis: split at the median of the distinct vertices' coordinates; a triangle goes left if
+    // ANY vertex is <= split; keep the axis whose left fraction is closest to 1/2 (first wins ties)
+    float bestRatio = 10;
+    int bestDim = 0;
+    float bestSplit = 0;
+    for (int dim = 0; dim < 3; dim++) {
+        coords.resize(uniq.size());
+        for (size_t i = 0; i < uniq.size(); i++) coords[i] = vertexPositionList[uniq[i]][dim];
+        size_t mid = coords.size() >> 1;
+        std::nth_element(coords.begin(), coords.begin() + mid, coords.end());
+        float split = coords[mid];
+        size_t left = 0;
+        for (size_t i = begin; i < end; i++) {
+            const vec3ui& v = triangleList[order[i]].vertexIndices;
+            left += (vertexPositionList[v.x][dim] <= split) | (vertexPositionList[v.y][dim] <= split) |
+                    (vertexPositionList[v.z][dim] <= split);
+        }
+        float ratio = (unsigned)left / float(count);
+        // the reference compares in double: abs(ratio - 0.5) with a double literal (KDTree.cpp:191)
+        if (std::fabs((double)ratio - 0.5) < std::fabs((double)bestRatio - 0.5)) {
+            bestRatio = ratio;
+            bestDim = dim;
+            bestSplit = split;
+        }
+    }
+    if (bestRatio == 0 || bestRatio == 1) {  // KDTree.cpp:199-203: no useful split, multi-triangle leaf
+        makeLeaf();
+        return;
+    }
+    auto goesLeft = [&](unsigned t) {
+        const vec3ui& v = triangleList[t].vertexIndices;
+        return vertexPositionList[v.x][bestDim] <= bestSplit || vertexPositionList[v.y][bestDim] <= bestSplit ||
+               vertexPositionList[v.z][bestDim] <= bestSplit;
+    };
+    size_t mid = std::stable_partition(order.begin() + begin, order.begin() + end, goesLeft) - order.begin();
+    buildNode(order, begin, mid, level + 1, stamp, stampGen, uniq, coords);
+    nodeRight[me] = (int32_t)nodeRight.size();
+    buildNode(order, mid, end, level + 1, stamp, stampGen, uniq, coords);
+}
+
+void KDTree::build() {
+    nodeMin.clear();
+    nodeMax.clear();
+    nodeRight.clear();
+    nodeLeafBegin.clear();
+    nodeLeafEnd.clear();
+    slotTid.clear();
+    depth = 0;
+    if (triangleList.empty()) return;
+    for (auto& t : triangleList)
+        for (int k = 0; k < 3; k++)
+            if (t.vertexIndices[k] >= vertexPositionList.size())
+                throw std::runtime_error("KDTree::build: vertex index out of range");
+    std::vector<unsigned> order(triangleList.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (unsigned)i;
+    std::vector<unsigned> stamp(vertexPositionList.size(), 0), uniq;
+    std::vector<float> coords;
+    unsigned gen = 0;
+    buildNode(order, 0, order.size(), 0, stamp, gen, uniq, coords);
+    slotTid.assign(order.begin(), order.end());
+}
+
+}  // namespace mirt_host

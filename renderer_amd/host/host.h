@@ -1,0 +1,244 @@
+// host.h — the host surface of the renderer, kept in the reference's own shape (Scene / Ray /
+// Camera / SceneObject / KDTree / MCRenderer / ConfigManager / Renderer, same method names and
+// argument meaning) so that a user of the reference finds the calls they know. Everything that
+// was a CPU or OpenGL hot loop behind these calls now goes through the C-ABI of include/mirt.h:
+//   IntersectionGPU::init / loadKDTreeToShader / query  (IntersectionGPU.h:40-45)
+//        -> IntersectionHIP::init / loadKDTreeToDevice / query
+//   PathTracer::renderPixels                              (PathTracer.cpp:4-58)
+//        -> PathTracerHIP::renderPixels
+// There is no CPU intersection or CPU path tracer in this library: without a GPU these calls fail.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mirt.h"
+#include "vecmath.h"
+#include "xml_lite.h"
+
+namespace mirt_host {
+
+class Scene;
+class SceneObject;
+
+// Ray.h:8-61 — the fields the batched GPU path reads or fills
+class Ray {
+public:
+    vec3f origin;
+    vec3f direction;  // terminated if length < 0.5 (Ray.h:16)
+    vec3f color;
+    float directionProb, originProb;
+    SceneObject* insideObject;
+    SceneObject* contactObject;
+    unsigned contactObjectTriangleID;
+    int current_tid, intersect_tid;
+    int pixelID;
+    SceneObject* intersectObject;  // filled outside scatter()
+    unsigned intersectObjectTriangleID;
+    float intersectDist;
+    Ray()
+        : color(1, 1, 1), directionProb(1), originProb(1), insideObject(nullptr), contactObject(nullptr),
+          contactObjectTriangleID(0), current_tid(-1), intersect_tid(-1), pixelID(-1),
+          intersectObject(nullptr), intersectObjectTriangleID(0), intersectDist(-1) {}
+};
+
+// SimpleShape.h:18-61 — mesh + transform; .obj loading with the reference loader's rules
+class SimpleShape {
+public:
+    std::string name;
+    vec3f minCoord, maxCoord;
+    std::vector<vec3f> vertexList, vertexNormalList, vertexTexCoordList;
+    std::vector<vec3ui> faceVertexIndexList, faceVertexNormalIndexList, faceVertexTexCoordIndexList;
+    matrix4 transform;
+    virtual ~SimpleShape() {}
+    void setTransform(const matrix4& mat) { transform = mat; }
+    matrix4 getTransform() const { return transform; }
+    vec3f getWorldVertexPosition(int vi) const { return transform.apply(vertexList[vi], 1.f); }
+    vec3ui getVertexIndices(int ti) const { return faceVertexIndexList[ti]; }
+    unsigned getVertexNum() const { return (unsigned)vertexList.size(); }
+    unsigned getTriangleNum() const { return (unsigned)faceVertexIndexList.size(); }
+    void getBoundingBox(vec3f& lo, vec3f& hi) const;
+    // throws std::runtime_error when the file cannot be read or is not a triangle .obj
+    void loadShape(const std::string& fileName, bool normalize = true);
+    void unitize();
+    // world-space corner normals of face fi, transformed by transpose(inverse(transform)) and NOT
+    // normalised (what SimpleShape::getWorldNormal interpolates, SimpleShape.cpp:310,317-323);
+    // false when the shape has no usable vertex normals (flat shading)
+    bool getWorldCornerNormals(unsigned fi, vec3f out[3]) const;
+    bool hasVertexNormals() const;
+};
+
+// SceneObject.h:19-89 + the Scene*Object wrappers: one object = mesh + one material description
+class SceneObject : public SimpleShape {
+public:
+    Scene* scene;
+    int objectIndex;
+    MirtObject material;  // type + parameters, what the device shades with
+    explicit SceneObject(Scene* scene);
+    bool emissive() const { return material.type == MIRT_OBJ_EMISSIVE; }
+    bool isVolumetric() const { return material.volumetric != 0; }
+    float getRefrCoeff() const;
+};
+
+// KDTree.h:10-72 — same build rules (median split, BEST strategy, KDTree.cpp:129-246), built
+// directly into the pre-order arrays that KDTree::serializeForGPU (KDTree.cpp:346-383) produces.
+class KDTree {
+public:
+    struct Ray {
+        vec3f origin, direction;
+    };
+    struct ObjSourceInformation {
+        unsigned objID, triangleID;
+    };
+    struct Triangle {
+        vec3ui vertexIndices;
+        ObjSourceInformation sourceInformation;
+    };
+    std::vector<vec3f> vertexPositionList;
+    std::vector<Triangle> triangleList;
+    // flattened, pre-order; left child of inner node i is i+1
+    std::vector<float> nodeMin, nodeMax;  // 3 per node
+    std::vector<int32_t> nodeRight, nodeLeafBegin, nodeLeafEnd, slotTid;
+    int depth = 0;
+    void build();
+    void destroy();
+    bool built() const { return !nodeRight.empty(); }
+    vec3f getDiagonal() const;
+    int numNodes() const { return (int)nodeRight.size(); }
+
+private:
+    void buildNode(std::vector<unsigned>& order, size_t begin, size_t end, int level,
+                   std::vector<unsigned>& stamp, unsigned& stampGen, std::vector<unsigned>& uniq,
+                   std::vector<float>& coords);
+};
+
+// Camera.h:12-30
+class Camera {
+public:
+    vec3f focus, position, up;
+    unsigned sightDist = 0;
+    int width = 0, height = 0;
+    MirtCamera toMirt() const;
+};
+
+// IntersectionGPU.h:12-46 — the batch closest-hit service, now HIP
+class IntersectionHIP {
+public:
+    struct Ray {
+        vec3f origin, direction;
+        int last_tid;
+    };
+    struct Hit {  // vec4f(dist, tid, 0, 0) in the reference (Intersection.frag:83)
+        float dist;
+        int tid;
+    };
+    // throws std::runtime_error on failure (the reference exit(1)s, Shader.cpp:9-12)
+    static void init(int device = 0);
+    static void shutdown();
+    static MirtContext* context();
+    static void loadKDTreeToDevice(const Scene& scene);
+    // mode MIRT_MODE_LAST_TID with ray.last_tid, like IntersectionGPU::query
+    static std::vector<Hit> query(const std::vector<Ray>& rays);
+    // general form: aux per ray, any MIRT_MODE_*
+    static std::vector<Hit> query(const std::vector<Ray>& rays, int mode);
+};
+
+// Scene.h:10-107 — the parts on the path
+class Scene {
+public:
+    typedef KDTree::ObjSourceInformation ObjSourceInformation;
+    KDTree tree;
+    std::vector<unsigned> objTriangleOffsetMap;
+    std::vector<SceneObject*> objects;
+    bool useGPU = true;  // the HIP path is the only one this library has
+    // flattened per-triangle data (by global triangle id), filled by buildKDTree
+    std::vector<float> triPos;       // 9 per triangle
+    std::vector<int32_t> triObj, triLocal;
+    std::vector<float> triVn;        // 9 per triangle
+    std::vector<MirtObject> objectDescs;
+    ~Scene();
+    void setGPU(bool on) { useGPU = on; }
+    bool usingGPU() const { return useGPU; }
+    void clear();
+    void buildKDTree(bool upload = true);
+    MirtSceneDesc describe() const;  // pointers stay valid until the scene changes
+    float intersect(const Ray& ray, ObjSourceInformation& objSource);  // unconditional, 1-ray batch
+    void fillIntersectObject(std::vector<Ray>& rays);                  // Scene.cpp:431-453
+    int getContactTreeTid(const Ray& ray) const;                       // Scene.cpp:420-429
+    vec3f getDiagonal() const { return tree.getDiagonal(); }
+};
+
+class Renderer;
+
+// MCRenderer.h:12-119
+class MCRenderer {
+protected:
+    Renderer* renderer;
+    std::string savePath;
+    unsigned maxDepth;
+    int outputIter;
+
+public:
+    explicit MCRenderer(Renderer* r) : renderer(r), maxDepth(20), outputIter(5) {}
+    virtual ~MCRenderer() {}
+    void setMaxDepth(int d) { maxDepth = (unsigned)d; }
+    int getMaxDepth() const { return (int)maxDepth; }
+    void setSavePath(const std::string& p) { savePath = p; }
+    const std::string& getSavePath() const { return savePath; }
+    virtual std::vector<vec3f> renderPixels(const Camera& camera);
+    // PFM writer with the reference's layout (MCRenderer.cpp:500-518)
+    static void saveImagePFM(const std::string& fileName, const std::vector<vec3f>& pixels, int w, int h);
+    static bool loadImagePFM(const std::string& fileName, std::vector<vec3f>& pixels, int& w, int& h);
+};
+
+// PathTracer.h / PathTracer.cpp:4-58 with the sample loop on the GPU. spp is configurable here
+// (the reference's is hard-wired to "forever", PathTracer.h:7,14).
+class PathTracerHIP : public MCRenderer {
+public:
+    unsigned spp = 64;
+    unsigned seed = 1;
+    unsigned sppPerLaunch = 0;
+    MirtRenderStats lastStats{};
+    explicit PathTracerHIP(Renderer* r) : MCRenderer(r) {}
+    std::vector<vec3f> renderPixels(const Camera& camera) override;
+};
+
+// ConfigManager.h:20-70
+class ConfigManager {
+public:
+    explicit ConfigManager(Renderer* r) : renderer(r) {}
+    void load(const std::string& configFilePath);
+    std::string getRootPath() const { return rootFolder; }
+
+private:
+    Renderer* renderer;
+    std::string rootFolder, currentPath;
+    std::map<std::string, std::unique_ptr<XmlDocument>> path_doc;
+    XmlNode* findNode(const std::string& filePath, const std::string& nodeTag, const std::string& nodeName);
+    XmlNode* findNode(XmlNode* root, const std::string& nodeTag, const std::string& nodeName);
+    std::pair<std::string, std::string> getPathAndName(XmlNode* node);
+    SceneObject* generateSceneObject(XmlNode* nodeObj, XmlNode* nodeMat);
+    std::string resolve(const std::string& path) const;
+};
+
+// Renderer.h:10-32
+class Renderer {
+public:
+    Scene scene;
+    Camera camera;
+    MCRenderer* mcRenderer = nullptr;
+    ConfigManager* configManager;
+    bool uploadOnLoad = true;  // tests that only inspect the host data switch this off
+    Renderer();
+    ~Renderer();
+    void loadConfig(const std::string& configFilePath);
+    std::vector<vec3f> render();
+    Camera& getCamera() { return camera; }
+};
+
+// xmlHelper.cpp:4-23
+matrix4 readMatrix(const char* value);
+vec3f readVec(const char* value);
+
+}  // namespace mirt_host

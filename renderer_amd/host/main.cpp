@@ -1,0 +1,42 @@
+// main.cpp — command-line shell in the shape of the reference's main.cpp:10-17 / Renderer.cpp:52-62:
+// load a config, render, write the PFM. Usage: mirt_render [Data/Config.xml] [--spp N] [--seed S] [--out file.pfm]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "host.h"
+
+using namespace mirt_host;
+
+int main(int argc, char** argv) {
+    std::string config = "Data/Config.xml", out;
+    unsigned spp = 0, seed = 0;
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--spp") && i + 1 < argc) spp = (unsigned)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = (unsigned)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
+        else config = argv[i];
+    }
+    try {
+        Renderer renderer;
+        renderer.loadConfig(config);
+        PathTracerHIP* pt = dynamic_cast<PathTracerHIP*>(renderer.mcRenderer);
+        if (pt && spp) pt->spp = spp;
+        if (pt && seed) pt->seed = seed;
+        if (!out.empty()) renderer.mcRenderer->setSavePath(out);
+        std::vector<vec3f> px = renderer.render();
+        if (pt) {
+            const MirtRenderStats& st = pt->lastStats;
+            printf("samples %llu rays %llu gpu %.3f ms (intersect %.3f ms) -> %.2f Msamples/s %.2f Mrays/s\n",
+                   (unsigned long long)st.n_samples, (unsigned long long)st.n_rays, st.gpu_ms, st.intersect_ms,
+                   st.n_samples / st.gpu_ms * 1e-3, st.n_rays / st.gpu_ms * 1e-3);
+        }
+        IntersectionHIP::shutdown();
+    } catch (const std::exception& e) {
+        fprintf(stderr, "mirt_render: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

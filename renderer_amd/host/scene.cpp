@@ -1,0 +1,207 @@
+// scene.cpp — Scene (tree build + flattening for the device), Camera, IntersectionHIP.
+#include <cstring>
+#include <stdexcept>
+
+#include "host.h"
+
+namespace mirt_host {
+
+MirtCamera Camera::toMirt() const {
+    MirtCamera c;
+    c.width = width;
+    c.height = height;
+    c.sight_dist = sightDist;
+    for (int k = 0; k < 3; k++) {
+        c.position[k] = position[k];
+        c.focus[k] = focus[k];
+        c.up[k] = up[k];
+    }
+    return c;
+}
+
+// ---- IntersectionHIP: the static service IntersectionGPU was (IntersectionGPU.cpp:5-14) -----------
+static MirtContext* g_ctx = nullptr;
+
+void IntersectionHIP::init(int device) {
+    if (g_ctx) return;
+    int rc = mirt_create(device, &g_ctx);
+    if (rc != MIRT_OK)
+        throw std::runtime_error(std::string("IntersectionHIP::init: ") + mirt_last_error(nullptr));
+}
+
+void IntersectionHIP::shutdown() {
+    if (g_ctx) mirt_destroy(g_ctx);
+    g_ctx = nullptr;
+}
+
+MirtContext* IntersectionHIP::context() { return g_ctx; }
+
+void IntersectionHIP::loadKDTreeToDevice(const Scene& scene) {
+    if (!g_ctx) throw std::runtime_error("IntersectionHIP::loadKDTreeToDevice: init() was not called");
+    MirtSceneDesc d = scene.describe();
+    if (mirt_upload_scene(g_ctx, &d) != MIRT_OK)
+        throw std::runtime_error(std::string("IntersectionHIP::loadKDTreeToDevice: ") + mirt_last_error(g_ctx));
+}
+
+std::vector<IntersectionHIP::Hit> IntersectionHIP::query(const std::vector<Ray>& rays, int mode) {
+    if (!g_ctx) throw std::runtime_error("IntersectionHIP::query: init() was not called");
+    const size_t n = rays.size();
+    std::vector<Hit> hits(n);
+    if (n == 0) return hits;
+    // AoS records -> the plane-major SoA the device reads
+    std::vector<float> o(3 * n), d(3 * n), t(n);
+    std::vector<int32_t> aux(n), tid(n);
+    for (size_t i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) {
+            o[c * n + i] = rays[i].origin[c];
+            d[c * n + i] = rays[i].direction[c];
+        }
+        aux[i] = rays[i].last_tid;
+    }
+    if (mirt_intersect(g_ctx, o.data(), d.data(), aux.data(), n, mode, t.data(), tid.data()) != MIRT_OK)
+        throw std::runtime_error(std::string("IntersectionHIP::query: ") + mirt_last_error(g_ctx));
+    for (size_t i = 0; i < n; i++) hits[i] = Hit{t[i], tid[i]};
+    return hits;
+}
+
+std::vector<IntersectionHIP::Hit> IntersectionHIP::query(const std::vector<Ray>& rays) {
+    return query(rays, MIRT_MODE_LAST_TID);
+}
+
+// ---- Scene ------------------------------------------------------------------------------------------
+Scene::~Scene() { clear(); }
+
+void Scene::clear() {
+    for (SceneObject* o : objects) delete o;
+    objects.clear();
+    tree.destroy();
+    objTriangleOffsetMap.clear();
+    triPos.clear();
+    triObj.clear();
+    triLocal.clear();
+    triVn.clear();
+    objectDescs.clear();
+}
+
+// Scene::buildKDTree (Scene.cpp:248-285): concatenate every object's world-space vertices and
+// index-shifted triangles, remember (objID, triangleID) per global triangle, build the tree; then
+// hand the flattened tree to the device (the reference does the same for its GL path, :276-284).
+void Scene::buildKDTree(bool upload) {
+    tree.destroy();
+    objTriangleOffsetMap.clear();
+    triPos.clear();
+    triObj.clear();
+    triLocal.clear();
+    triVn.clear();
+    objectDescs.clear();
+    unsigned vi_offset = 0, tri_offset = 0;
+    for (unsigned oi = 0; oi < objects.size(); oi++) {
+        SceneObject* obj = objects[oi];
+        obj->objectIndex = (int)oi;
+        for (unsigned i = 0; i < obj->getVertexNum(); i++)
+            tree.vertexPositionList.push_back(obj->getWorldVertexPosition((int)i));
+        const bool smooth = obj->hasVertexNormals();
+        for (unsigned i = 0; i < obj->getTriangleNum(); i++) {
+            KDTree::Triangle tri;
+            vec3ui v = obj->getVertexIndices((int)i);
+            tri.vertexIndices = vec3ui{v.x + vi_offset, v.y + vi_offset, v.z + vi_offset};
+            tri.sourceInformation.objID = oi;
+            tri.sourceInformation.triangleID = i;
+            tree.triangleList.push_back(tri);
+            for (int k = 0; k < 3; k++) {
+                const vec3f& p = tree.vertexPositionList[tri.vertexIndices[k]];
+                triPos.push_back(p.x);
+                triPos.push_back(p.y);
+                triPos.push_back(p.z);
+            }
+            triObj.push_back((int32_t)oi);
+            triLocal.push_back((int32_t)i);
+            vec3f vn[3];
+            if (smooth) obj->getWorldCornerNormals(i, vn);
+            for (int k = 0; k < 3; k++) {
+                triVn.push_back(vn[k].x);
+                triVn.push_back(vn[k].y);
+                triVn.push_back(vn[k].z);
+            }
+        }
+        MirtObject m = obj->material;
+        m.has_vn = smooth ? 1 : 0;
+        m.tri_begin = (int32_t)tri_offset;
+        m.tri_count = (int32_t)obj->getTriangleNum();
+        obj->material = m;
+        objectDescs.push_back(m);
+        objTriangleOffsetMap.push_back(tri_offset);
+        tri_offset += obj->getTriangleNum();
+        vi_offset += obj->getVertexNum();
+    }
+    tree.build();
+    if (useGPU && upload) {
+        IntersectionHIP::init();
+        IntersectionHIP::loadKDTreeToDevice(*this);
+    }
+}
+
+MirtSceneDesc Scene::describe() const {
+    MirtSceneDesc d;
+    memset(&d, 0, sizeof d);
+    d.struct_size = sizeof d;
+    d.n_nodes = tree.numNodes();
+    d.node_min = tree.nodeMin.data();
+    d.node_max = tree.nodeMax.data();
+    d.node_right = tree.nodeRight.data();
+    d.node_leaf_begin = tree.nodeLeafBegin.data();
+    d.node_leaf_end = tree.nodeLeafEnd.data();
+    d.n_tris = (int32_t)tree.triangleList.size();
+    d.slot_tid = tree.slotTid.data();
+    d.tri_pos = triPos.data();
+    d.tri_obj = triObj.data();
+    d.tri_local = triLocal.data();
+    d.tri_vn = triVn.data();
+    d.n_objects = (int32_t)objectDescs.size();
+    d.objects = objectDescs.data();
+    return d;
+}
+
+// Scene::intersect (Scene.cpp:341-352) without a condition, as a one-ray batch on the device.
+float Scene::intersect(const Ray& ray, ObjSourceInformation& objSource) {
+    std::vector<IntersectionHIP::Ray> one(1);
+    one[0].origin = ray.origin;
+    one[0].direction = ray.direction;
+    one[0].last_tid = -1;
+    IntersectionHIP::Hit h = IntersectionHIP::query(one, MIRT_MODE_UNCONDITIONAL)[0];
+    if (h.dist >= 0) objSource = tree.triangleList[h.tid].sourceInformation;
+    return h.dist;
+}
+
+int Scene::getContactTreeTid(const Ray& ray) const {
+    if (ray.contactObject)
+        for (size_t i = 0; i < objects.size(); i++)
+            if (ray.contactObject == objects[i]) return (int)(objTriangleOffsetMap[i] + ray.contactObjectTriangleID);
+    return -1;
+}
+
+// Scene::fillIntersectObject (Scene.cpp:431-453). The reference's GL path can only skip the
+// triangle the ray starts on (last_tid); here rays that carry contact/inside objects use the CPU
+// branch's NoSelfIntersectionCondition, which is what image parity is defined against.
+void Scene::fillIntersectObject(std::vector<Ray>& rays) {
+    std::vector<IntersectionHIP::Ray> q(rays.size());
+    for (size_t i = 0; i < rays.size(); i++) {
+        q[i].origin = rays[i].origin;
+        q[i].direction = rays[i].direction;
+        int contact = rays[i].contactObject ? rays[i].contactObject->objectIndex : -1;
+        int inside = rays[i].insideObject ? rays[i].insideObject->objectIndex : -1;
+        q[i].last_tid = MIRT_PACK_IDS(contact, inside);
+    }
+    std::vector<IntersectionHIP::Hit> hits = IntersectionHIP::query(q, MIRT_MODE_NO_SELF);
+    for (size_t i = 0; i < rays.size(); i++) {
+        if (hits[i].dist >= 0) {
+            const ObjSourceInformation& osi = tree.triangleList[hits[i].tid].sourceInformation;
+            rays[i].intersectObject = objects[osi.objID];
+            rays[i].intersectDist = hits[i].dist;
+            rays[i].intersectObjectTriangleID = osi.triangleID;
+            rays[i].intersect_tid = hits[i].tid;
+        }
+    }
+}
+
+}  // namespace mirt_host
