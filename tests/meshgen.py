@@ -1,0 +1,138 @@
+"""Procedural scenes for tests and the large-mesh benchmark: displaced
+icospheres with diffuse / glossy / refractive materials inside Cornell walls. Nothing is committed;
+meshes are generated from a seed at run time."""
+import numpy as np
+
+import renderer_amd as ra
+
+
+def icosphere(level):
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2],
+                  [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5],
+                  [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], np.int64)
+    for _ in range(level):
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        e.sort(axis=1)
+        key = e[:, 0] * (len(v) + 1) + e[:, 1]
+        uniq, inv = np.unique(key, return_inverse=True)
+        a, b = uniq // (len(v) + 1), uniq % (len(v) + 1)
+        mid = v[a] + v[b]
+        mid /= np.linalg.norm(mid, axis=1, keepdims=True)
+        m = inv.reshape(3, -1) + len(v)  # midpoints of edges 01, 12, 20 per face
+        v = np.concatenate([v, mid])
+        f = np.concatenate([np.stack([f[:, 0], m[0], m[2]], 1), np.stack([f[:, 1], m[1], m[0]], 1),
+                            np.stack([f[:, 2], m[2], m[1]], 1), np.stack([m[0], m[1], m[2]], 1)])
+    return v, f
+
+
+def _fbm(p, seed, octaves=4):
+    rng = np.random.default_rng(seed)
+    out = np.zeros(len(p))
+    amp, freq = 0.5, 2.0
+    for _ in range(octaves):
+        w = rng.normal(size=(3, 3)) * freq
+        ph = rng.uniform(0, 2 * np.pi, 3)
+        out += amp * np.sin(p @ w[0] + ph[0]) * np.sin(p @ w[1] + ph[1]) * np.sin(p @ w[2] + ph[2])
+        amp *= 0.5
+        freq *= 2.0
+    return out
+
+
+def displaced_sphere(level, seed, radius, center, amp=0.15):
+    v, f = icosphere(level)
+    r = 1.0 + amp * _fbm(v, seed)
+    v = v * r[:, None] * radius + np.asarray(center, np.float64)
+    return v, f
+
+
+def vertex_normals(v, f):
+    fn = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    vn = np.zeros_like(v)
+    for k in range(3):
+        np.add.at(vn, f[:, k], fn)
+    vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-30)
+    return vn
+
+
+def _quad(p0, p1, p2, p3, normal):
+    """two triangles whose face normal (p1-p0)x(p2-p0) equals `normal`'s direction"""
+    v = np.array([p0, p1, p2, p3], np.float64)
+    f = np.array([[0, 1, 2], [0, 2, 3]], np.int64)
+    n = np.cross(v[1] - v[0], v[2] - v[0])
+    if np.dot(n, normal) < 0:
+        f = f[:, [0, 2, 1]]
+    return v, f, np.tile(np.asarray(normal, np.float64), (4, 1))
+
+
+def _obj(kind, color=(1, 1, 1), coeff=0.0, ior=1.0, decay=(1, 1, 1), has_vn=1):
+    o = np.zeros(1, ra.OBJECT_DTYPE)[0]
+    o["type"] = kind
+    o["has_vn"] = has_vn
+    o["color"] = color
+    o["coeff"] = coeff
+    o["ior"] = ior
+    o["decay"] = decay
+    return o
+
+
+def cornell_with_meshes(level, seed=7, smooth=True):
+    """Light + 5 walls + three displaced spheres (diffuse, glossy 5, glass 1.5).
+    Returns dict(verts, tris, tri_obj, tri_vn, objects) ready for HostScene.from_arrays."""
+    parts = []  # (verts, faces, vertex normals, object)
+    a = 0.2
+    parts.append(_quad((-a, 0.99, -a), (a, 0.99, -a), (a, 0.99, a), (-a, 0.99, a), (0, -1, 0)) +
+                 (_obj(ra.OBJ_EMISSIVE, (50, 50, 50)),))
+    parts.append(_quad((-1, -1, -1), (-1, -1, 1), (-1, 1, 1), (-1, 1, -1), (1, 0, 0)) +
+                 (_obj(ra.OBJ_DIFFUSE, (0.75, 0.25, 0.25)),))
+    parts.append(_quad((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1), (-1, 0, 0)) +
+                 (_obj(ra.OBJ_DIFFUSE, (0.25, 0.25, 0.75)),))
+    parts.append(_quad((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1), (0, -1, 0)) +
+                 (_obj(ra.OBJ_DIFFUSE, (0.5, 0.5, 0.5)),))
+    parts.append(_quad((-1, -1, -1), (1, -1, -1), (1, -1, 1), (-1, -1, 1), (0, 1, 0)) +
+                 (_obj(ra.OBJ_DIFFUSE, (0.5, 0.5, 0.5)),))
+    parts.append(_quad((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (0, 0, 1)) +
+                 (_obj(ra.OBJ_DIFFUSE, (0.25, 0.75, 0.25)),))
+    mats = [_obj(ra.OBJ_DIFFUSE, (0.7, 0.7, 0.3)), _obj(ra.OBJ_GLOSSY, (0.75, 0.75, 0.75), coeff=5.0),
+            _obj(ra.OBJ_REFRACTIVE, (1, 1, 1), ior=1.5)]
+    centers = [(-0.5, -0.55, -0.3), (0.0, 0.1, -0.45), (0.5, -0.55, 0.2)]
+    for k in range(3):
+        v, f = displaced_sphere(level, seed + k, 0.36, centers[k])
+        vn = vertex_normals(v, f)
+        parts.append((v, f, vn, mats[k]))
+    verts, tris, tri_obj, tri_vn, objects = [], [], [], [], []
+    off = 0
+    for oi, (v, f, vn, ob) in enumerate(parts):
+        verts.append(v)
+        tris.append(f + off)
+        tri_obj.append(np.full(len(f), oi, np.int32))
+        tri_vn.append(vn[f].reshape(len(f), 9))
+        ob = ob.copy()
+        ob["has_vn"] = 1 if smooth else 0
+        objects.append(ob)
+        off += len(v)
+    return dict(verts=np.concatenate(verts).astype(np.float32), tris=np.concatenate(tris).astype(np.uint32),
+                tri_obj=np.concatenate(tri_obj), tri_vn=np.concatenate(tri_vn).astype(np.float32),
+                objects=np.array(objects, ra.OBJECT_DTYPE))
+
+
+def mesh_scene(level, seed=7, smooth=True):
+    m = cornell_with_meshes(level, seed, smooth)
+    return ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"], m["objects"],
+                                    m["tri_vn"] if smooth else None)
+
+
+def random_rays(n, seed, n_objects, inside_obj=-1):
+    """half camera-like rays from (0,0,2), half interior rays; plus packed ids for mode 2"""
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-0.9, 0.9, size=(3, n)).astype(np.float32)
+    o[:, : n // 2] = np.array([[0.0], [0.0], [2.0]], np.float32)
+    d = rng.normal(size=(3, n)).astype(np.float32)
+    d[2, : n // 2] = -np.abs(d[2, : n // 2]) - 2.0
+    d /= np.linalg.norm(d, axis=0, keepdims=True)
+    contact = rng.integers(-1, n_objects, n)
+    inside = np.where(rng.random(n) < 0.8, -1, inside_obj)
+    return o, d.astype(np.float32), ra.pack_ids(contact, inside)

@@ -1,0 +1,218 @@
+"""GPU parity tests of the closest-hit kernel, through the C-ABI, against the CPU oracle.
+Bar (BASELINE.json north_star): hit id equal on >= 99.99 % of rays, t within 1e-5 relative; the
+kernel is built to be bit-exact, so the tests also report and bound the exact-match rate."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import meshgen
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(tg, ig, tc, ic, what):
+    match = (ig == ic).mean()
+    assert match >= 0.9999, "%s: id parity %.6f" % (what, match)
+    both = (ig == ic) & (ic >= 0)
+    assert np.allclose(tg[both], tc[both], rtol=1e-5, atol=0), what
+    assert (tg[ic < 0][ig[ic < 0] < 0] < 0).all()
+    return float(match), float((tg[both] == tc[both]).mean())
+
+
+@pytest.fixture(scope="module")
+def cornell_dev(gpu, cornell):
+    gpu.upload(cornell.describe())
+    return gpu
+
+
+def test_cornell_all_modes(cornell_dev, cornell, cornell_oracle, ra):
+    o, d, aux = meshgen.random_rays(300000, 21, cornell.n_objects, inside_obj=2)
+    last = np.random.default_rng(1).integers(-1, cornell.n_tris, o.shape[1]).astype(np.int32)
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_LAST_TID, last), (ra.MODE_NO_SELF, aux)):
+        tg, ig = cornell_dev.intersect(o, d, a, mode)
+        tc, ic = cornell_oracle.intersect(o, d, a, mode, threads=16)
+        m, ex = _check(tg, ig, tc, ic, "cornell mode %d" % mode)
+        assert m == 1.0 and ex == 1.0  # bit-exact on this scene
+
+
+def test_path_vertex_rays(cornell_dev, cornell, cornell_oracle, ra):
+    """Secondary rays as the path tracer issues them (origins ON surfaces, no epsilon offset,
+    contact/inside ids set): the case the NoSelfIntersection predicate exists for."""
+    cam = cornell.camera()
+    rays = []
+    for pixel in range(0, 128 * 128, 3):
+        verts, _, n = cornell_oracle.trace_path(cam, pixel, 1)
+        for k in range(1, min(n, len(verts))):
+            if np.linalg.norm(verts[k][3:6]) > 0.5:
+                rays.append(verts[k][:6])
+    rays = np.array(rays, np.float32)
+    o, d = rays[:, :3].T.copy(), rays[:, 3:6].T.copy()
+    # ids: recover the contact object from the origin by an unconditional probe backwards is fragile;
+    # instead sweep every (contact, inside) combination that occurs in this scene on the same rays
+    for contact, inside in ((-1, -1), (3, -1), (6, -1), (2, 2), (2, -1), (1, -1), (5, 2)):
+        aux = ra.pack_ids(np.full(len(rays), contact), np.full(len(rays), inside))
+        tg, ig = cornell_dev.intersect(o, d, aux, ra.MODE_NO_SELF)
+        tc, ic = cornell_oracle.intersect(o, d, aux, ra.MODE_NO_SELF, threads=16)
+        _check(tg, ig, tc, ic, "path rays contact=%d inside=%d" % (contact, inside))
+
+
+def test_mesh20k(gpu, mesh20k, mesh20k_oracle, ra):
+    gpu.upload(mesh20k.describe())
+    o, d, aux = meshgen.random_rays(200000, 33, mesh20k.n_objects, inside_obj=8)
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_NO_SELF, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = mesh20k_oracle.intersect(o, d, a, mode, threads=16)
+        _check(tg, ig, tc, ic, "mesh20k mode %d" % mode)
+
+
+def test_flat_shaded_mesh(gpu, ra, orc):
+    """objects without vertex normals use the face normal (SimpleShape.cpp:313-316,324-327)"""
+    s = meshgen.mesh_scene(3, smooth=False)
+    S = orc.OracleScene(s.raw())
+    gpu.upload(s.describe())
+    o, d, aux = meshgen.random_rays(100000, 44, s.n_objects, inside_obj=8)
+    tg, ig = gpu.intersect(o, d, aux, ra.MODE_NO_SELF)
+    tc, ic = S.intersect(o, d, aux, ra.MODE_NO_SELF, threads=16)
+    _check(tg, ig, tc, ic, "flat mesh")
+    S.close()
+    s.close()
+
+
+def test_edge_cases(cornell_dev, cornell, cornell_oracle, ra):
+    # empty batch
+    t, i = cornell_dev.intersect(np.zeros((3, 0), np.float32), np.zeros((3, 0), np.float32))
+    assert len(t) == 0 and len(i) == 0
+    # axis-parallel rays (zero direction components are skipped by the box test), rays starting on
+    # walls, rays through box corners, a zero direction, a ragged batch size (not a multiple of 64)
+    o = np.array([[0, 0, 2], [0, 0, 0], [-1, 0, 0], [0, -1, 0], [0.3, 0.99, 0.1], [0, 0, 0], [5, 5, 5],
+                  [0, 0, 2], [-1, -1, -1], [0.2, 0.2, 0.2], [0, 0, 0]], np.float32).T.copy()
+    d = np.array([[0, 0, -1], [1, 0, 0], [1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 0], [1, 0, 0],
+                  [-1, -1, -3], [1, 1, 1], [0, 0, 1], [0, 1, 0]], np.float32).T.copy()
+    for mode, a in ((0, None), (2, ra.pack_ids(np.full(11, -1), np.full(11, -1)))):
+        tg, ig = cornell_dev.intersect(o, d, a, mode)
+        tc, ic = cornell_oracle.intersect(o, d, a, mode, threads=1)
+        assert np.array_equal(ig, ic) and np.array_equal(tg, tc)
+    assert ic[5] == -1 and ic[6] == -1  # zero direction and a ray leaving the scene miss
+
+
+def test_large_batch_properties(cornell_dev, cornell, ra):
+    """full-size properties that need no oracle: determinism, permutation invariance, and a hit
+    point that lies on the hit triangle's plane"""
+    n = 1 << 22
+    o, d, aux = meshgen.random_rays(n, 55, cornell.n_objects, inside_obj=2)
+    t1, i1 = cornell_dev.intersect(o, d, aux, ra.MODE_NO_SELF)
+    t2, i2 = cornell_dev.intersect(o, d, aux, ra.MODE_NO_SELF)
+    assert np.array_equal(t1, t2) and np.array_equal(i1, i2)
+    perm = np.random.default_rng(2).permutation(n)
+    t3, i3 = cornell_dev.intersect(o[:, perm].copy(), d[:, perm].copy(), aux[perm], ra.MODE_NO_SELF)
+    assert np.array_equal(t3, t1[perm]) and np.array_equal(i3, i1[perm])
+    raw = cornell.raw()
+    hit = i1 >= 0
+    v = raw["verts"][raw["tris"][i1[hit]].astype(np.int64)].astype(np.float64)
+    p = (o[:, hit] + d[:, hit] * t1[hit]).T.astype(np.float64)
+    nrm = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    assert np.abs(((p - v[:, 0]) * nrm).sum(1)).max() < 1e-4
+    assert hit.mean() > 0.8
+
+
+def test_counts_match_ordered_restatement(cornell_dev, cornell, cornell_oracle, ra):
+    """The instrumented kernel's box / triangle test counts equal the CPU restatement of the same
+    traversal order (they feed the algorithmic-bytes figure of bench.py)."""
+    import torch
+
+    n = 50000
+    o, d, aux = meshgen.random_rays(n, 66, cornell.n_objects, inside_obj=2)
+    to, do_, ta = (torch.from_numpy(x).cuda() for x in (o, d, aux))
+    tt = torch.empty(n, dtype=torch.float32, device="cuda")
+    ti = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for mode in (0, 2):
+        nb, nt = cornell_dev.intersect_count_dev(to.data_ptr(), do_.data_ptr(), ta.data_ptr(), n, mode,
+                                                 tt.data_ptr(), ti.data_ptr())
+        t2, i2, cb, ct = cornell_oracle.intersect_ordered(o, d, aux, mode)
+        assert (nb, nt) == (cb, ct)
+        assert np.array_equal(ti.cpu().numpy(), i2) and np.array_equal(tt.cpu().numpy(), t2)
+        rb, rt = cornell_oracle.ref_counts(o[:, :5000], d[:, :5000], aux[:5000], mode)
+        assert nb / n < rb / 5000 and nt / n < rt / 5000
+
+
+def test_device_pointer_entry_and_streams(cornell_dev, cornell, cornell_oracle, ra):
+    import torch
+
+    n = 100001
+    o, d, aux = meshgen.random_rays(n, 77, cornell.n_objects, inside_obj=2)
+    to, do_, ta = (torch.from_numpy(x).cuda() for x in (o, d, aux))
+    tt = torch.empty(n, dtype=torch.float32, device="cuda")
+    ti = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    cornell_dev.intersect_dev(to.data_ptr(), do_.data_ptr(), ta.data_ptr(), n, ra.MODE_NO_SELF, tt.data_ptr(),
+                              ti.data_ptr(), C.c_void_p(st))
+    torch.cuda.synchronize()
+    tc, ic = cornell_oracle.intersect(o, d, aux, ra.MODE_NO_SELF, threads=16)
+    assert np.array_equal(ti.cpu().numpy(), ic) and np.array_equal(tt.cpu().numpy(), tc)
+
+
+def test_generate_rays_matches_camera(cornell_dev, cornell, orc, ra):
+    import torch
+
+    cam = cornell.camera()
+    wh = cam.width * cam.height
+    spp = 3
+    to = torch.empty((3, wh * spp), dtype=torch.float32, device="cuda")
+    td = torch.empty_like(to)
+    torch.cuda.synchronize()
+    cornell_dev.generate_rays_dev(cam, 5, spp, 9, to.data_ptr(), td.data_ptr())
+    o, d = to.cpu().numpy(), td.cpu().numpy()
+    assert (o.T == (0, 0, 2)).all()
+    rng = np.random.default_rng(0)
+    for i in rng.integers(0, wh * spp, 300):
+        pixel, sample = int(i % wh), 5 + int(i // wh)
+        u = (orc.rng_draw(9, pixel, sample, 0) >> 8) / 2.0**24
+        v = (orc.rng_draw(9, pixel, sample, 1) >> 8) / 2.0**24
+        assert np.array_equal(d[:, i], orc.camera_ray(cam, pixel, u, v))
+
+
+def test_upload_validation(gpu, cornell, ra):
+    """malformed descriptors are rejected on the host; nothing is launched"""
+    d = cornell.describe()
+    tree = cornell.tree()
+    bad = tree["node_right"].copy()
+    bad[0] = cornell.n_nodes + 5
+    d.node_right = bad.ctypes.data_as(C.c_void_p).value
+    with pytest.raises(ra.MirtError, match="right child"):
+        gpu.upload(d)
+    d = cornell.describe()
+    bad = tree["slot_tid"].copy()
+    bad[3] = bad[4]
+    d.slot_tid = bad.ctypes.data_as(C.c_void_p).value
+    with pytest.raises(ra.MirtError, match="permutation"):
+        gpu.upload(d)
+    d = cornell.describe()
+    d.struct_size = 8
+    with pytest.raises(ra.MirtError, match="struct_size"):
+        gpu.upload(d)
+    fresh = ra.Device(device=0)
+    with pytest.raises(ra.MirtError, match="no scene"):
+        fresh.intersect(np.zeros((3, 4), np.float32), np.ones((3, 4), np.float32))
+    fresh.close()
+    gpu.upload(cornell.describe())
+    with pytest.raises(ra.MirtError, match="NULL"):
+        gpu.intersect(np.zeros((3, 4), np.float32), np.ones((3, 4), np.float32), None, ra.MODE_NO_SELF)
+
+
+def test_host_surface_fill_intersect(cornell, cornell_oracle, ra):
+    """Scene::fillIntersectObject through IntersectionHIP (the reference's seam, Scene.cpp:431-453)"""
+    cornell.upload()
+    o, d, _ = meshgen.random_rays(20000, 88, cornell.n_objects)
+    rng = np.random.default_rng(3)
+    contact = rng.integers(-1, cornell.n_objects, 20000).astype(np.int32)
+    inside = np.where(rng.random(20000) < 0.8, -1, 2).astype(np.int32)
+    dist, tid, obj, local = cornell.fill_intersect(o.T.copy(), d.T.copy(), contact, inside)
+    tc, ic = cornell_oracle.intersect(o, d, ra.pack_ids(contact, inside), ra.MODE_NO_SELF, threads=16)
+    assert np.array_equal(tid, ic) and np.array_equal(dist, tc)
+    raw = cornell.raw()
+    hit = ic >= 0
+    assert np.array_equal(obj[hit], raw["tri_obj"][ic[hit]]) and np.array_equal(local[hit], raw["tri_local"][ic[hit]])
+    assert (obj[~hit] == -1).all()

@@ -1,0 +1,172 @@
+"""CPU tests of the host surface (XML/OBJ loading, tree build + flatten) and of the C-ABI library's
+exports. No compute call is made here: there is no GPU in this environment."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import meshgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA = os.path.join(ROOT, "Data")
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mirth?_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(ra):
+    L = C.CDLL(ra.LIB_PATH)
+    for header, known in (("mirt.h", ra.MIRT_SYMBOLS), ("mirt_host.h", ra.MIRTH_SYMBOLS)):
+        names = _declared(header)
+        assert sorted(known) == names, "bindings out of date for %s" % header
+        for n in names:
+            assert hasattr(L, n), "libmirt.so does not export %s" % n
+
+
+def test_no_gpu_means_error_not_fallback(ra):
+    """Without a device mirt_create must fail with MIRT_E_NO_DEVICE; nothing computes on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    rc = ra.lib().mirt_create(0, C.byref(ctx))
+    assert rc == -2 and not ctx.value
+    assert b"no CPU path" in ra.lib().mirt_last_error(None)
+    with pytest.raises(ra.MirtError):
+        ra.Device(device=0)
+
+
+def test_config_load_cornell(cornell, ra):
+    assert (cornell.n_objects, cornell.n_tris, cornell.n_verts) == (8, 1932, 988)
+    raw = cornell.raw()
+    ob = raw["objects"]
+    assert ob["type"].tolist() == [ra.OBJ_EMISSIVE, ra.OBJ_REFRACTIVE, ra.OBJ_REFRACTIVE, ra.OBJ_DIFFUSE,
+                                   ra.OBJ_DIFFUSE, ra.OBJ_DIFFUSE, ra.OBJ_GLOSSY, ra.OBJ_DIFFUSE]
+    assert ob["ior"][1] == -1.0 and ob["ior"][2] == 1.5  # Reflective = mirror, Refractive 1.5
+    assert np.allclose(ob["color"][0], 50) and np.allclose(ob["color"][3], (0.75, 0.25, 0.25))
+    assert ob["coeff"][6] == 5.0 and np.allclose(ob["decay"][2], 1)
+    assert ob["tri_begin"].tolist() == [0, 2, 962, 1922, 1924, 1926, 1928, 1930]
+    assert (ob["has_vn"] == 1).all()
+    # readMatrix is row-major text (xmlHelper.cpp:4-16): the light is 0.4 x 0.4 at y = 0.99
+    lv = raw["verts"][:4]
+    assert np.allclose(lv[:, 1], 0.99) and np.allclose(np.abs(lv[:, [0, 2]]), 0.2)
+    # ball 1: radius 0.4 around (-0.5,-0.6,-0.3)
+    bv = raw["verts"][4:4 + 482]
+    assert np.allclose(np.linalg.norm(bv - (-0.5, -0.6, -0.3), axis=1), 0.4, atol=1e-6)
+    # normals go through the inverse-transpose: the mirrored light faces down, left wall faces +x
+    assert np.allclose(raw["tri_vn"][0].reshape(3, 3), (0, -5, 0))
+    assert np.allclose(raw["tri_vn"][1922].reshape(3, 3), (1, 0, 0))
+    cam = cornell.camera()
+    assert (cam.width, cam.height, cam.sight_dist) == (128, 128, 87)
+    assert list(cam.position) == [0, 0, 2] and list(cam.up) == [0, 1, 0]
+    assert cornell.render_cfg() == dict(max_depth=20, spp=64, seed=1)
+
+
+def test_product_tree_equals_oracle_tree(cornell, cornell_oracle, mesh20k, mesh20k_oracle):
+    """Two independent builds (array/stable-partition in the product, pointer/recursive in the
+    oracle) of KDTree::splitBest + serializeForGPU must agree bit for bit."""
+    for s, o in ((cornell, cornell_oracle), (mesh20k, mesh20k_oracle)):
+        a, b = s.tree(), o.flatten()
+        assert s.n_nodes == o.n_nodes and s.depth == o.depth
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+
+
+def test_describe_is_consistent(cornell, ra):
+    d = cornell.describe()
+    assert d.struct_size == C.sizeof(ra.SceneDesc) and d.n_tris == 1932 and d.n_objects == 8
+    assert d.n_nodes == cornell.n_nodes
+
+
+def test_config_errors(ra, tmp_path):
+    with pytest.raises(ra.MirtError, match="cannot open"):
+        ra.HostScene.load_config(str(tmp_path / "missing.xml"))
+    cfg = tmp_path / "c.xml"
+    cfg.write_text("<Config><Scene><path>%s/Scene_CornellBox.xml</path><name>Balls</name><camera>c1</camera>"
+                   "</Scene><Renderer><type>VCM</type></Renderer></Config>" % DATA)
+    # relative mesh / material paths resolve against the config's folder, so copy the data folder layout
+    os.symlink(os.path.join(DATA, "objs"), tmp_path / "objs")
+    os.symlink(os.path.join(DATA, "Materials.xml"), tmp_path / "Materials.xml")
+    with pytest.raises(ra.MirtError, match="outside this build"):
+        ra.HostScene.load_config(str(cfg))
+    bad = tmp_path / "bad.xml"
+    bad.write_text("<Config><Scene></Config>")
+    with pytest.raises(ra.MirtError, match="xml"):
+        ra.HostScene.load_config(str(bad))
+    cfg2 = tmp_path / "c2.xml"
+    cfg2.write_text("<Config><Scene><path>%s/Scene_CornellBox.xml</path><name>NoSuchScene</name><camera>c1</camera>"
+                    "</Scene><Renderer><type>PT</type></Renderer></Config>" % DATA)
+    # an unknown name falls back to the first scene without a Name -> none here -> error
+    with pytest.raises(ra.MirtError, match="not found"):
+        ra.HostScene.load_config(str(cfg2))
+
+
+def test_inline_material_and_obj_rules(ra, tmp_path):
+    """OBJ loader rules (SimpleShape.cpp:65-189): '#' skipped, 4-token lines only, a//n and plain
+    faces, unitize to [-1,1]; inline <Material> fallback (ConfigManager.cpp:230-235)."""
+    (tmp_path / "t.obj").write_text("# comment\nv 0 0 0\nv 4 0 0\nv 0 2 0\nv 0 0 1 9\nvn 0 0 1\nvt 0.5 0.5\n"
+                                    "f 1 2 3\nf 1 3\ng grp\nf 1//1 3//1 4//1\n")
+    (tmp_path / "s.xml").write_text("""<Scene Name="S"><Camera Name="c"><width>8</width><height>4</height>
+      <sightDist>6</sightDist><focus>(0, 0, 0)</focus><position>(0, 0, 3)</position><up>(0, 1, 0)</up></Camera>
+      <Object><filePath>t.obj</filePath><Material><type>Glossy</type><color>(0.1, 0.2, 0.3)</color>
+      <coeff>7</coeff></Material></Object></Scene>""")
+    (tmp_path / "c.xml").write_text("<Config><Scene><path>s.xml</path><name>S</name><camera>c</camera></Scene>"
+                                    "<renderer>PT</renderer><maxDepth>5</maxDepth></Config>")
+    s = ra.HostScene.load_config(str(tmp_path / "c.xml"))
+    raw = s.raw()
+    assert s.n_tris == 2 and s.n_verts == 4  # "f 1 3" has 3 tokens -> dropped; "v 0 0 1 9" keeps 3 numbers
+    # the last face carried normals but the first did not -> normal index list is short -> flat shading
+    assert raw["objects"]["has_vn"][0] == 0
+    assert raw["objects"]["type"][0] == ra.OBJ_GLOSSY and raw["objects"]["coeff"][0] == 7
+    # unitize: centre (2,1,0.5), longest extent 4 -> x in [-1,1]
+    assert np.allclose(raw["verts"][:, 0].min(), -1) and np.allclose(raw["verts"][:, 0].max(), 1)
+    assert np.allclose(raw["verts"][3], (-1, -0.5, 0.25))
+    assert s.render_cfg()["max_depth"] == 5
+    cam = s.camera()
+    assert (cam.width, cam.height, cam.sight_dist) == (8, 4, 6)
+    s.close()
+
+
+def test_scene_from_arrays_validation(ra):
+    m = meshgen.cornell_with_meshes(1)
+    with pytest.raises(ra.MirtError, match="out of range"):
+        bad = m["tris"].copy()
+        bad[0, 0] = 10**6
+        ra.HostScene.from_arrays(m["verts"], bad, m["tri_obj"], m["objects"], m["tri_vn"])
+    with pytest.raises(ra.MirtError, match="ordered"):
+        ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"][::-1].copy(), m["objects"], m["tri_vn"])
+    s = ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"], m["objects"], m["tri_vn"])
+    assert s.n_objects == 9 and s.n_tris == 12 + 3 * 80
+    ob = s.raw()["objects"]
+    assert ob["tri_count"].tolist() == [2] * 6 + [80] * 3
+    s.close()
+
+
+def test_pfm_roundtrip(ra, tmp_path):
+    img = np.random.default_rng(0).random((5, 7, 3)).astype(np.float32)
+    p = str(tmp_path / "a.pfm").encode()
+    assert ra.lib().mirth_save_pfm(p, img.ctypes.data_as(C.c_void_p), 7, 5) == 0
+    data = open(p, "rb").read()
+    assert data.startswith(b"PF\n7 5\n-1.000000\n")  # MCRenderer.cpp:505
+    body = np.frombuffer(data[len(b"PF\n7 5\n-1.000000\n"):], "<f4").reshape(5, 7, 3)
+    assert np.array_equal(body[::-1], img)  # rows bottom-to-top, channels R,G,B
+    back = np.zeros_like(img)
+    wh = (C.c_int32 * 2)()
+    assert ra.lib().mirth_load_pfm(p, back.ctypes.data_as(C.c_void_p), 35, C.byref(wh)) == 0
+    assert list(wh) == [7, 5] and np.array_equal(back, img)
+
+
+def test_pack_ids_and_shards(ra):
+    a = ra.pack_ids([-1, 0, 7, 65533], [-1, 3, -1, 65533])
+    assert a.view(np.uint32).tolist() == [0, 1 | (4 << 16), 8, 65534 | (65534 << 16)]
+    for spp, ws in ((4096, 8), (10, 4), (3, 8), (64, 1)):
+        parts = [ra.shard_samples(spp, ws, r) for r in range(ws)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == spp
+        for (b0, c0), (b1, _) in zip(parts, parts[1:]):
+            assert b0 + c0 == b1

@@ -1,0 +1,258 @@
+"""CPU tests of the oracle itself: hand-derived known answers and invariants. The reference holds
+no fixtures for this path and cannot be built here, so these pins are ours
+("parity unpinned")."""
+import numpy as np
+import pytest
+
+import meshgen
+from conftest import rmse
+
+
+def test_box_known_answers(orc):
+    lo, hi = (-1, -1, -1), (1, 1, 1)
+    # from outside along +x: enters at x=-1 after distance 2
+    assert orc.box_intersect(lo, hi, (-3, 0, 0), (1, 0, 0)) == 2.0
+    # from inside: the reference returns the EXIT distance (planes behind have t < 0), KDTree.cpp:44
+    assert orc.box_intersect(lo, hi, (0, 0, 0), (1, 0, 0)) == 1.0
+    # pointing away: miss
+    assert orc.box_intersect(lo, hi, (-3, 0, 0), (-1, 0, 0)) == -1.0
+    # parallel to the slab and outside it: miss (zero components are skipped, KDTree.cpp:40)
+    assert orc.box_intersect(lo, hi, (-3, 2, 0), (1, 0, 0)) == -1.0
+    # flat box (an axis-aligned wall): hit through its own plane
+    assert orc.box_intersect((-1, 0, -1), (1, 0, 1), (0.25, 2, 0.5), (0, -1, 0)) == 2.0
+    # inclusive compares: a ray through the box corner edge still hits
+    assert orc.box_intersect(lo, hi, (-3, 1, 1), (1, 0, 0)) == 2.0
+
+
+def test_triangle_known_answers(orc):
+    v0, v1, v2 = (0, 0, 0), (1, 0, 0), (0, 1, 0)
+    assert orc.tri_intersect(v0, v1, v2, (0.25, 0.25, 1), (0, 0, -1)) == 1.0
+    # two-sided (KDTree.cpp:280-281 accepts either winding)
+    assert orc.tri_intersect(v0, v1, v2, (0.25, 0.25, -2), (0, 0, 1)) == 2.0
+    # behind the origin
+    assert orc.tri_intersect(v0, v1, v2, (0.25, 0.25, 1), (0, 0, 1)) == -1.0
+    # outside the triangle
+    assert orc.tri_intersect(v0, v1, v2, (0.75, 0.75, 1), (0, 0, -1)) == -1.0
+    # parallel to the plane
+    assert orc.tri_intersect(v0, v1, v2, (0.25, 0.25, 1), (1, 0, 0)) == -1.0
+    # on an edge: inclusive sign tests accept it
+    assert orc.tri_intersect(v0, v1, v2, (0.5, 0.0, 1), (0, 0, -1)) == 1.0
+    # t == 0 is accepted (origin on the plane)
+    assert orc.tri_intersect(v0, v1, v2, (0.25, 0.25, 0), (0, 0, -1)) == 0.0
+
+
+def test_rng_reference_values(orc):
+    def lowbias32(x):
+        x &= 0xFFFFFFFF
+        x ^= x >> 16
+        x = (x * 0x7FEB352D) & 0xFFFFFFFF
+        x ^= x >> 15
+        x = (x * 0x846CA68B) & 0xFFFFFFFF
+        x ^= x >> 16
+        return x
+
+    for seed, pixel, sample, dim in [(1, 0, 0, 0), (1, 12345, 7, 3), (99, 2**20 - 1, 4095, 40)]:
+        h1 = lowbias32(sample + 0x9E3779B9 * (seed + 1))
+        key = lowbias32(pixel ^ h1)
+        assert orc.rng_draw(seed, pixel, sample, dim) == lowbias32(key + 0x9E3779B9 * dim)
+    # uniformity of the 24-bit floats over dimensions and samples
+    u = np.array([orc.rng_draw(1, 17, s, d) >> 8 for s in range(200) for d in range(20)]) / 2.0**24
+    assert 0.0 <= u.min() and u.max() < 1.0
+    assert abs(u.mean() - 0.5) < 0.02 and abs(u.var() - 1 / 12) < 0.01
+
+
+def test_camera_ray(orc, ra):
+    cam = ra.make_camera(512, 512, 350)
+    # Camera.cpp:15-22 at the image centre with u = v = 0: direction is exactly -z
+    d = orc.camera_ray(cam, 256 * 512 + 256, 0.0, 0.0)
+    assert np.allclose(d, (0, 0, -1))
+    # pixel (0,0), u=v=0.5: right*(0.5-256) + up*(256-0.5) + front*350
+    d = orc.camera_ray(cam, 0, 0.5, 0.5)
+    e = np.array([-255.5, 255.5, -350.0])
+    assert np.allclose(d, e / np.linalg.norm(e), atol=1e-6)
+
+
+def test_hemi_cos_distribution(orc):
+    # RandGenerator.cpp:152-168: +Y is the pole; cos(theta) = u2^(1/(k+1))
+    rng = np.random.default_rng(3)
+    for k in (1.0, 5.0):
+        u = rng.random((4000, 2)).astype(np.float32)
+        dirs = np.array([orc.hemi_cos(k, a, b) for a, b in u])
+        assert np.allclose(np.linalg.norm(dirs, axis=1), 1, atol=1e-5)
+        assert (dirs[:, 1] >= 0).all()
+        # E[cos] for pdf ~ cos^k over the hemisphere = (k+1)/(k+2)
+        assert abs(dirs[:, 1].mean() - (k + 1) / (k + 2)) < 0.01
+    assert np.allclose(orc.hemi_cos(1.0, 0.0, 1.0), (0, 1, 0), atol=1e-6)
+
+
+def test_tree_invariants(cornell_oracle):
+    f = cornell_oracle.flatten()
+    N, T = cornell_oracle.n_nodes, len(cornell_oracle.tris)
+    leaf = f["node_right"] < 0
+    assert (f["leaf_begin"][leaf] < f["leaf_end"][leaf]).all()
+    # every triangle in exactly one leaf (KDTree.cpp:208-224), slots contiguous in pre-order
+    assert sorted(f["slot_tid"].tolist()) == list(range(T))
+    assert f["leaf_begin"][leaf][0] == 0 and f["leaf_end"][leaf][-1] == T
+    assert (f["leaf_begin"][leaf][1:] == f["leaf_end"][leaf][:-1]).all()
+    # node boxes are the tight bounds of their triangles
+    v = cornell_oracle.verts[cornell_oracle.tris.astype(np.int64)]  # [T,3,3]
+    for i in np.nonzero(leaf)[0][:200]:
+        tv = v[f["slot_tid"][f["leaf_begin"][i]:f["leaf_end"][i]]].reshape(-1, 3)
+        assert np.array_equal(tv.min(0), f["node_min"][i]) and np.array_equal(tv.max(0), f["node_max"][i])
+    assert (f["node_right"][~leaf] > np.nonzero(~leaf)[0] + 1).all() and (f["node_right"] < N).all()
+
+
+def _brute_force(verts, tris, o, d):
+    """independent numpy closest hit over ALL triangles with the reference's triangle test order"""
+    f32 = np.float32
+    v = verts[tris.astype(np.int64)]  # [T,3,3]
+    n = o.shape[1]
+    best_t = np.full(n, -1, f32)
+    best_id = np.full(n, -1, np.int32)
+
+    def dot(a, b):
+        r = (a[..., 0] * b[..., 0]).astype(f32)
+        r = (r + (a[..., 1] * b[..., 1]).astype(f32)).astype(f32)
+        return (r + (a[..., 2] * b[..., 2]).astype(f32)).astype(f32)
+
+    def cross(l, r):
+        return np.stack([(l[..., 1] * r[..., 2]).astype(f32) - (l[..., 2] * r[..., 1]).astype(f32),
+                         (l[..., 2] * r[..., 0]).astype(f32) - (l[..., 0] * r[..., 2]).astype(f32),
+                         (l[..., 0] * r[..., 1]).astype(f32) - (l[..., 1] * r[..., 0]).astype(f32)], -1).astype(f32)
+
+    O = o.T[:, None, :]
+    D = d.T[:, None, :]
+    pos = np.ones((n, len(tris)), bool)
+    neg = np.ones((n, len(tris)), bool)
+    for i in range(3):
+        line = (v[:, (i + 1) % 3] - v[:, i])[None]
+        r2v = (v[:, i][None] - O).astype(f32)
+        s = dot(D, cross(np.broadcast_to(line, r2v.shape), r2v))
+        pos &= s >= 0
+        neg &= s <= 0
+    nrm = cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 1])
+    ln = np.sqrt(dot(nrm, nrm)).astype(f32)
+    nrm = np.where(ln[:, None] > 0, (nrm / np.where(ln > 0, ln, 1)[:, None]).astype(f32), nrm)
+    od = dot(nrm[None], r2v)
+    dd = dot(nrm[None], D)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = (od / dd).astype(f32)
+    ok = (dd != 0) & ~(q < 0) & (pos | neg)
+    q = np.where(ok, q, np.inf)
+    best_id = q.argmin(1).astype(np.int32)
+    best_t = q[np.arange(n), best_id]
+    miss = ~np.isfinite(best_t)
+    return np.where(miss, -1, best_t).astype(f32), np.where(miss, -1, best_id)
+
+
+def test_tree_traversal_equals_brute_force(cornell_oracle):
+    """The tree only prunes: away from box-boundary rounding the closest hit equals the closest
+    over all triangles (checked with an independent numpy restatement of the triangle test)."""
+    o, d, _ = meshgen.random_rays(1500, 11, 8)
+    t, tid = cornell_oracle.intersect(o, d, None, 0, threads=4)
+    bt, bid = _brute_force(cornell_oracle.verts, cornell_oracle.tris, o, d)
+    same = tid == bid
+    # differences must be ties (equal t) or box-rounding misses, and rare
+    assert same.mean() > 0.995
+    diff = ~same
+    tie = np.isclose(t[diff], bt[diff], rtol=1e-5, atol=1e-6) | (tid[diff] < 0)
+    assert tie.all()
+    assert np.array_equal(t[same], bt[same])
+
+
+def test_ordered_traversal_matches_reference_order(cornell_oracle, mesh20k_oracle):
+    """The product's traversal order (near child first, distance pruning, explicit tie rule) must
+    return what the reference's both-children order returns."""
+    for orc_scene, nobj in ((cornell_oracle, 8), (mesh20k_oracle, 9)):
+        o, d, aux = meshgen.random_rays(20000, 5, nobj, inside_obj=2 if nobj == 8 else 8)
+        for mode, a in ((0, None), (2, aux)):
+            t, tid = orc_scene.intersect(o, d, a, mode, threads=8)
+            t2, tid2, nb, nt = orc_scene.intersect_ordered(o, d, a, mode)
+            assert np.array_equal(tid, tid2) and np.array_equal(t, t2)
+            rb, rt = orc_scene.ref_counts(o[:, :2000], d[:, :2000], None if a is None else a[:2000], mode)
+            assert nb / 20000 < rb / 2000  # pruning visits fewer boxes than the reference order
+
+
+def test_predicate_cases(cornell_oracle):
+    """NoSelfIntersectionCondition.cpp:12-27 on the floor (object 6, normal +y)."""
+    S = cornell_oracle
+    tid = int(np.nonzero(S.tri_obj == 6)[0][0])
+    down, up = (0, -1, 0), (0, 1, 0)
+    o_above, o_below = (0.1, -0.5, 0.1), (0.1, -1.5, 0.1)
+    # no contact, not inside anything: front hit from above is legal, back hit from below is not
+    assert S.legal(tid, o_above, down, 0.5, -1, -1) is True
+    assert S.legal(tid, o_below, up, 0.5, -1, -1) is True  # inside == contact == NULL: only "in && contact==hit"
+    # contact = some other object, inside NULL: back faces of everything are ignored
+    assert S.legal(tid, o_below, up, 0.5, 3, -1) is False
+    assert S.legal(tid, o_above, down, 0.5, 3, -1) is True
+    # leaving the floor itself (contact = floor): re-hitting its front side from above is legal
+    assert S.legal(tid, o_above, down, 0.5, 6, -1) is True
+    # inside == contact == floor: an "in" hit on the floor is rejected
+    assert S.legal(tid, o_above, down, 0.5, 6, 6) is False
+    assert S.legal(tid, o_below, up, 0.5, 6, 6) is True
+
+
+def test_world_normals(cornell_oracle):
+    S = cornell_oracle
+    # the left wall uses a reflecting transform; its shading normal must point into the box (+x)
+    tid = int(np.nonzero(S.tri_obj == 3)[0][0])
+    assert np.allclose(S.world_normal(tid, (-1, 0, 0)), (1, 0, 0), atol=1e-6)
+    # light faces down
+    assert np.allclose(S.world_normal(0, (0, 0.99, 0)), (0, -1, 0), atol=1e-6)
+    # mirror ball: smooth normal at a vertex equals the radial direction
+    c = np.array([-0.5, -0.6, -0.3])
+    tid = int(np.nonzero(S.tri_obj == 1)[0][100])
+    p = S.verts[S.tris[tid][0]]
+    n = S.world_normal(tid, p)
+    assert np.allclose(n, (p - c) / np.linalg.norm(p - c), atol=1e-4)
+
+
+def test_path_semantics(cornell_oracle, cornell):
+    """samplePath bookkeeping: a path that scores ends on the emitter, camera vertex first."""
+    cam = cornell.camera()
+    scored = 0
+    for pixel in range(0, 128 * 128, 97):
+        verts, rgb, n = cornell_oracle.trace_path(cam, pixel, 0)
+        assert 2 <= n <= 23  # camera vertex + <= maxDepth+1 scatters + terminator
+        assert np.allclose(verts[0][:3], (0, 0, 2)) and verts[0][9] == 1.0
+        if rgb.sum() > 0:
+            scored += 1
+            last = verts[n - 1]
+            assert np.allclose(last[3:6], 0) and np.allclose(last[6:9], 50)  # emission, terminated
+            assert abs(last[1] - 0.99) < 1e-5  # on the light plane
+    assert scored > 0
+
+
+def test_render_statistics(cornell_oracle, cornell):
+    """independent seeds agree in the mean; the same seed reproduces bit for bit; shards add up"""
+    cam = cornell.camera()
+    a, ra_ = cornell_oracle.render(cam, 8, seed=1, threads=8)
+    b, _ = cornell_oracle.render(cam, 8, seed=1, threads=3)
+    assert np.array_equal(a, b)
+    c, _ = cornell_oracle.render(cam, 8, seed=2, threads=8)
+    assert abs(a.mean() - c.mean()) / a.mean() < 0.1
+    lo, _ = cornell_oracle.render(cam, 3, spp_begin=0, seed=1, threads=8)
+    hi, _ = cornell_oracle.render(cam, 5, spp_begin=3, seed=1, threads=8)
+    assert np.allclose(lo + hi, a, rtol=1e-5, atol=1e-6)
+    assert 2.0 < ra_ / (128 * 128 * 8) < 5.0  # a few rays per sample (~3.14)
+
+
+def test_furnace_energy(orc, ra):
+    """Known answer for the integrator: inside a closed diffuse box lit by one emissive wall the
+    mean radiance seen is bounded by emission * albedo series; with a black box only directly
+    visible emitter pixels are non-zero and equal the emission exactly (after vignetting)."""
+    m = meshgen.cornell_with_meshes(1)
+    objs = m["objects"].copy()
+    objs["color"][1:] = 0.0  # everything but the light is black
+    objs["type"][6:] = ra.OBJ_DIFFUSE
+    raw = dict(verts=m["verts"], tris=m["tris"], tri_obj=m["tri_obj"], tri_local=np.zeros(len(m["tris"]), np.int32),
+               tri_vn=m["tri_vn"], objects=objs)
+    S = orc.OracleScene(raw)
+    cam = ra.make_camera(64, 64, 40, position=(0, 0.5, 0.9), focus=(0, 0.99, 0), up=(0, 0, -1))
+    img, _ = S.render(cam, 4, seed=1, threads=8)
+    img /= 4
+    centre = img[32, 32]
+    # straight at the light: contribution = cos0 * emission / vignette(centre) with cos0 ~ 1
+    assert np.allclose(centre, 50, rtol=2e-3)
+    assert img.max() <= 50 * 1.01  # pixel jitter moves |front.dir| against the centre value
+    S.close()
