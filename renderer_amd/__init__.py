@@ -68,6 +68,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("renderer_amd: %s is missing; build it with `make -C renderer_amd` "
                                "(or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+        # torch ships its own HIP runtime (same SONAME as /opt/rocm's). Two HIP runtimes in one
+        # process cannot both see the GPU, so let torch's load first and libmirt.so bind to it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.mirt_last_error.restype = C.c_char_p
         L.mirt_last_error.argtypes = [C.c_void_p]

@@ -20,7 +20,7 @@ def _check(tg, ig, tc, ic, what):
     return float(match), float((tg[both] == tc[both]).mean())
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def cornell_dev(gpu, cornell):
     gpu.upload(cornell.describe())
     return gpu

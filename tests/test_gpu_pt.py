@@ -15,19 +15,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _parity(dev, oracle, cam, spp, seed=1):
+def _parity(dev, oracle, cam, spp, seed=1, same_tol=0.02, ray_tol=1e-4):
     g, st = dev.render_pt(cam, spp, seed=seed)
     c, nr = oracle.render(cam, spp, seed=seed, threads=16)
     c2, _ = oracle.render(cam, spp, seed=seed + 100, threads=16)
     noise = rmse(c / spp, c2 / spp)
     same = rmse(g / spp, c / spp)
     cross = rmse(g / spp, c2 / spp)
-    assert same <= 0.02 * noise, (same, noise)
+    assert same <= same_tol * noise, (same, noise)
     assert cross <= 1.15 * noise, (cross, noise)
     mg, mc = (g / spp).mean((0, 1)), (c / spp).mean((0, 1))
     assert (np.abs(mg - mc) / mc <= 0.01).all(), (mg, mc)
     # almost all paths are identical: the ray counts agree to 1e-4
-    assert abs(int(st.n_rays) - nr) / nr < 1e-4
+    assert abs(int(st.n_rays) - nr) / nr < ray_tol
     assert st.n_samples == cam.width * cam.height * spp
     return g, c
 
@@ -48,9 +48,24 @@ def test_other_scenes_image_parity(gpu, ra, orc):
         s.close()
 
 
-def test_mesh_scene_image_parity(gpu, mesh20k, mesh20k_oracle, ra):
+def test_mesh_scene_image_parity(gpu, mesh20k, mesh20k_oracle, ra, orc):
+    """Displaced spheres. Inside the bumpy GLASS one, rays are trapped by total internal reflection
+    for many bounces and every curved bounce amplifies a 1-ulp difference (device sinf/cosf/powf vs
+    libm), so a fraction f of paths takes another course; RMSE_same/RMSE_noise ~ sqrt(f). The bound
+    is therefore looser there (f <~ 2 %) and tight again when the glass is replaced by a diffuse
+    material on the same geometry."""
+    cam = ra.make_camera(96, 96, 65)
     gpu.upload(mesh20k.describe())
-    _parity(gpu, mesh20k_oracle, ra.make_camera(96, 96, 65), 16)
+    _parity(gpu, mesh20k_oracle, cam, 16, same_tol=0.15, ray_tol=5e-3)
+    m = meshgen.cornell_with_meshes(4)
+    m["objects"]["type"][8] = ra.OBJ_DIFFUSE
+    m["objects"]["color"][8] = (0.6, 0.6, 0.6)
+    s = ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"], m["objects"], m["tri_vn"])
+    S = orc.OracleScene(s.raw())
+    gpu.upload(s.describe())
+    _parity(gpu, S, cam, 16)
+    S.close()
+    s.close()
 
 
 def test_determinism_sharding_and_batching(gpu, cornell, ra):
