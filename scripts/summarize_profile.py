@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarises a scripts/profile_gpu.sh output directory into one text file (for profiles/).
+usage: summarize_profile.py gpurun_out/prof_r1 > profiles/r1_summary.txt"""
+import csv, glob, os, re, sys
+from collections import defaultdict
+
+d = sys.argv[1]
+def short(name):
+    name = re.sub(r"\(.*", "", name).replace("void ", "").replace("mirt::", "")
+    return name[:70]
+print("# rocprofv3 summary of: python3 bench.py --steps N --warmup 1 --no-cpu --pt-spp 8 (scripts/profile_gpu.sh)")
+for f in glob.glob(os.path.join(d, "kt", "*", "*_kernel_stats.csv")):
+    print("\n## kernel trace --stats (per kernel: calls, total ms, average us, % of GPU time)")
+    for r in csv.DictReader(open(f)):
+        if float(r["Percentage"]) < 0.05: continue
+        print("%-72s calls %5s total %10.3f ms avg %12.3f us  %6.2f%%" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+agg = defaultdict(lambda: defaultdict(float)); calls = defaultdict(lambda: defaultdict(int)); meta = {}
+for f in glob.glob(os.path.join(d, "*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if "k_" not in k: continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]] += 1
+        meta[k] = (r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"])
+print("\n## PMC counters, mean per dispatch (separate --pmc passes)")
+for k in sorted(agg):
+    m = meta[k]
+    print("\n%s  [wg %s, LDS %s B, VGPR %s, SGPR %s, scratch %s]" % ((k,) + m))
+    c = {n: agg[k][n] / calls[k][n] for n in agg[k]}
+    for n in sorted(c): print("    %-26s %18.1f   (dispatches %d)" % (n, c[n], calls[k][n]))
+    g = c.get
+    if g("SQ_WAVE_CYCLES"):
+        print("    -> wave-cycle split: active %.1f%%  wait_any %.1f%%  wait_inst %.1f%%" % (100 * g("SQ_ACTIVE_INST_ANY", 0) / g("SQ_WAVE_CYCLES"), 100 * g("SQ_WAIT_ANY", 0) / g("SQ_WAVE_CYCLES"), 100 * g("SQ_WAIT_INST_ANY", 0) / g("SQ_WAVE_CYCLES")))
+    if g("SQ_INSTS_VALU") and g("SQ_THREAD_CYCLES_VALU"):
+        print("    -> VALU lane utilisation (thread-cycles / (insts*64 lanes... see guide)): SQ_THREAD_CYCLES_VALU/SQ_INSTS_VALU = %.2f" % (g("SQ_THREAD_CYCLES_VALU") / g("SQ_INSTS_VALU")))
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and (g("TCC_HIT_sum") + g("TCC_MISS_sum")) > 0:
+        print("    -> L2 hit rate %.2f%%" % (100 * g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))))
+    if g("FETCH_SIZE") is not None:
+        print("    -> HBM-side read  : FETCH_SIZE %.1f KiB raw; x2 gfx950 correction for wide coalesced streams = %.3f MB" % (g("FETCH_SIZE"), 2 * g("FETCH_SIZE") * 1024 / 1e6))
+    if g("WRITE_SIZE") is not None:
+        print("    -> HBM-side write : WRITE_SIZE %.1f KiB = %.3f MB" % (g("WRITE_SIZE"), g("WRITE_SIZE") * 1024 / 1e6))
