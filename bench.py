@@ -30,6 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import renderer_amd as ra  # noqa: E402
+from renderer_amd.multi_gpu import reduce_radiance_sums  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 PRIMARY_SPP = 4
@@ -143,8 +144,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     pst = dev.render_pt_dev(cam, acc.data_ptr(), s_count, spp_begin=s_begin, seed=1)
-    if world > 1:
-        dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
+    reduce_radiance_sums(acc, dst=0)
     barrier()
     pt_elapsed = time.perf_counter() - t0
     pt_stats = torch.tensor([pt_elapsed, float(pst.n_rays), pst.gpu_ms, pst.intersect_ms], dtype=torch.float64,
