@@ -40,6 +40,9 @@ struct MirtContext {
     uint32_t* d_cnt = nullptr;   // [2] live-path counters (ping-pong)
     uint32_t* h_cnt = nullptr;   // pinned
     unsigned long long* d_counters = nullptr;  // [2] box / triangle test counters
+    uint32_t* d_queue = nullptr;               // ray queue head of the persistent intersect kernel
+    int n_cus = 256;
+    int max_blocks = 1024;                     // resident blocks of the intersect kernel (grid cap)
     // staging for the host-pointer intersect
     float* st_o = nullptr;
     float* st_d = nullptr;
@@ -127,10 +130,12 @@ int mirt_create(int device, MirtContext** out) {
                  prop.gcnArchName, prop.multiProcessorCount, (size_t)prop.sharedMemPerBlock,
                  prop.totalGlobalMem / 1073741824.0);
         ctx->info = buf;
+        ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     if ((e = hipMalloc(&ctx->d_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
         (e = hipHostMalloc(&ctx->h_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc(&ctx->d_counters, 2 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc(&ctx->d_counters, 2 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc(&ctx->d_queue, 64 * sizeof(uint32_t))) != hipSuccess) {
         g_create_err = std::string("mirt_create: ") + hipGetErrorString(e);
         delete ctx;
         return MIRT_E_HIP;
@@ -181,6 +186,7 @@ int mirt_destroy(MirtContext* ctx) {
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     hipFree(ctx->d_cnt);
     hipFree(ctx->d_counters);
+    hipFree(ctx->d_queue);
     if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -337,6 +343,13 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     // per-lane stack: (depth+1) levels x (node index, entry distance) x block lanes, in LDS
     ctx->block = (size_t)(depth + 1) * 8 * 256 <= 65536 ? 256 : 64;
     ctx->lds = (size_t)(depth + 1) * 8 * ctx->block;
+    // persistent grid: as many blocks as stay resident (a larger grid would only queue; smaller
+    // batches launch fewer). The occupancy answer is advisory, nothing waits on co-residency.
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_intersect<MIRT_MODE_NO_SELF, false, false>,
+                                                     ctx->block, ctx->lds) != hipSuccess || occ < 1)
+        occ = 1;
+    ctx->max_blocks = occ * ctx->n_cus;
     ctx->has_scene = true;
     ctx->has_unsupported = unsupported;
     return MIRT_OK;
@@ -347,23 +360,25 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
 // ---- launches -------------------------------------------------------------------------------------
 template <bool COUNT, bool SLOT_OUT>
 static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
-                            const int* aux, const uint32_t* n_ptr, uint32_t n_max, uint32_t stride,
-                            float* t_out, int* id_out) {
-    if (n_max == 0) return MIRT_OK;
-    dim3 block(ctx->block), grid((n_max + ctx->block - 1) / ctx->block);
+                            const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out) {
+    if (n == 0) return MIRT_OK;
+    const uint32_t want = (n + ctx->block - 1) / ctx->block;
+    dim3 block(ctx->block), grid(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks));
     unsigned long long* cnt = ctx->d_counters;
+    // the ray queue head must start at zero for every launch
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), st));
     switch (mode) {
         case MIRT_MODE_UNCONDITIONAL:
             hipLaunchKernelGGL((k_intersect<MIRT_MODE_UNCONDITIONAL, COUNT, SLOT_OUT>), grid, block,
-                               ctx->lds, st, ctx->sc, O, D, aux, n_ptr, n_max, stride, t_out, id_out, cnt);
+                               ctx->lds, st, ctx->sc, O, D, aux, n, stride, t_out, id_out, cnt, ctx->d_queue);
             break;
         case MIRT_MODE_LAST_TID:
             hipLaunchKernelGGL((k_intersect<MIRT_MODE_LAST_TID, COUNT, SLOT_OUT>), grid, block,
-                               ctx->lds, st, ctx->sc, O, D, aux, n_ptr, n_max, stride, t_out, id_out, cnt);
+                               ctx->lds, st, ctx->sc, O, D, aux, n, stride, t_out, id_out, cnt, ctx->d_queue);
             break;
         case MIRT_MODE_NO_SELF:
             hipLaunchKernelGGL((k_intersect<MIRT_MODE_NO_SELF, COUNT, SLOT_OUT>), grid, block,
-                               ctx->lds, st, ctx->sc, O, D, aux, n_ptr, n_max, stride, t_out, id_out, cnt);
+                               ctx->lds, st, ctx->sc, O, D, aux, n, stride, t_out, id_out, cnt, ctx->d_queue);
             break;
         default:
             return fail(ctx, MIRT_E_INVALID, "intersect: unknown mode");
@@ -393,7 +408,7 @@ int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* dire
     if (rc != MIRT_OK || n == 0) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    return launch_intersect<false, false>(ctx, st, mode, origins, directions, aux, nullptr, (uint32_t)n,
+    return launch_intersect<false, false>(ctx, st, mode, origins, directions, aux, (uint32_t)n,
                                           (uint32_t)n, t_out, tid_out);
 }
 
@@ -407,7 +422,7 @@ int mirt_intersect_count_dev(MirtContext* ctx, const float* origins, const float
     if (n == 0) return MIRT_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    rc = launch_intersect<true, false>(ctx, ctx->stream, mode, origins, directions, aux, nullptr,
+    rc = launch_intersect<true, false>(ctx, ctx->stream, mode, origins, directions, aux,
                                        (uint32_t)n, (uint32_t)n, t_out, tid_out);
     if (rc != MIRT_OK) return rc;
     unsigned long long h[2];
@@ -443,7 +458,7 @@ int mirt_intersect(MirtContext* ctx, const float* origins, const float* directio
         }
         if (mode != MIRT_MODE_UNCONDITIONAL)
             HIPCHK(ctx, hipMemcpyAsync(ctx->st_aux, aux + b, m * sizeof(int), hipMemcpyHostToDevice, st));
-        rc = launch_intersect<false, false>(ctx, st, mode, ctx->st_o, ctx->st_d, ctx->st_aux, nullptr,
+        rc = launch_intersect<false, false>(ctx, st, mode, ctx->st_o, ctx->st_d, ctx->st_aux,
                                             (uint32_t)m, (uint32_t)m, ctx->st_t, ctx->st_id);
         if (rc != MIRT_OK) return rc;
         HIPCHK(ctx, hipMemcpyAsync(t_out + b, ctx->st_t, m * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -535,7 +550,7 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
         if (!e0 || !e1) return fail(ctx, MIRT_E_HIP, "hipEventCreate failed");
         *ev_used += 2;
         HIPCHK(ctx, hipEventRecord(e0, st));
-        int rc = launch_intersect<false, true>(ctx, st, mode, pb->o, pb->d, pb->ids, nullptr, n, pb->stride,
+        int rc = launch_intersect<false, true>(ctx, st, mode, pb->o, pb->d, pb->ids, n, pb->stride,
                                                pb->t, pb->slot);
         if (rc != MIRT_OK) return rc;
         HIPCHK(ctx, hipEventRecord(e1, st));
