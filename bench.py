@@ -100,10 +100,11 @@ def main():
     torch.cuda.synchronize()
 
     # ---- algorithmic work of this batch (instrumented launch, never timed) -------------------------
-    pb, ptr_ = dev.intersect_count_dev(po.data_ptr(), pd.data_ptr(), None, n_pri, ra.MODE_UNCONDITIONAL,
-                                       pt_.data_ptr(), pi_.data_ptr())
-    sb, str_ = dev.intersect_count_dev(so.data_ptr(), sd.data_ptr(), sa.data_ptr(), n_sec, ra.MODE_NO_SELF,
-                                       st_.data_ptr(), si_.data_ptr())
+    pa = dev.intersect_audit_dev(po.data_ptr(), pd.data_ptr(), None, n_pri, ra.MODE_UNCONDITIONAL,
+                                 pt_.data_ptr(), pi_.data_ptr())
+    sa_ = dev.intersect_audit_dev(so.data_ptr(), sd.data_ptr(), sa.data_ptr(), n_sec, ra.MODE_NO_SELF,
+                                  st_.data_ptr(), si_.data_ptr())
+    pb, ptr_, sb, str_ = pa["box"], pa["tri"], sa_["box"], sa_["tri"]
     hit_rate = float(((pi_ >= 0).sum() + (si_ >= 0).sum()).item()) / n_rays
 
     def step(events=None):
@@ -179,6 +180,9 @@ def main():
                 "hit_rate": round(hit_rate, 4),
                 "box_tests_per_ray": round((pb + sb) / n_rays, 3),
                 "tri_tests_per_ray": round((ptr_ + str_) / n_rays, 3),
+                "classifier": {"unproven_box_fraction": round((pa["ambiguous"] + sa_["ambiguous"]) / (pb + sb), 5),
+                               "proven_decisions_disagreeing_with_exact_test": pa["mismatch"] + sa_["mismatch"],
+                               "chain_verifications_per_ray": round((pa["walks"] + sa_["walks"]) / n_rays, 5)},
                 "parallelism": "ray-sharded x%d, no collective" % world,
             },
         }

@@ -152,6 +152,13 @@ int mirt_intersect_count_dev(MirtContext* ctx, const float* origins, const float
                              const int32_t* aux, size_t n, int mode, float* t_out,
                              int32_t* tid_out, uint64_t* n_box_tests, uint64_t* n_tri_tests);
 
+/* Full audit of the same instrumented run: audit[0] node-box tests, [1] triangle tests, [2] boxes the
+ * slab classifier could not prove (entered and flagged), [3] proven decisions that DISAGREE with the
+ * exact reference box test evaluated beside them (must be 0), [4] ancestor-chain verifications.     */
+int mirt_intersect_audit_dev(MirtContext* ctx, const float* origins, const float* directions,
+                             const int32_t* aux, size_t n, int mode, float* t_out,
+                             int32_t* tid_out, uint64_t audit[5]);
+
 /* --- camera rays --------------------------------------------------------------------------
  * replaces Camera::generateRay (Camera.cpp:4-24) for a batch: ray i = (sample s, pixel p) with
  * i = (s - spp_begin) * W*H + p. DEVICE pointers float[3][n], n = spp_count*W*H.             */

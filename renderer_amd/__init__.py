@@ -51,7 +51,7 @@ class SceneDesc(C.Structure):
 
 # every symbol include/mirt.h and include/mirt_host.h declare (checked by the CPU tests)
 MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_scene", "mirt_intersect",
-                "mirt_intersect_dev", "mirt_intersect_count_dev", "mirt_generate_rays_dev", "mirt_render_pt",
+                "mirt_intersect_dev", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
                 "mirt_render_pt_dev", "mirt_capture_rays_dev", "mirt_device_info"]
 MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
@@ -93,6 +93,7 @@ def lib():
         L.mirt_intersect_dev.argtypes = L.mirt_intersect.argtypes + [C.c_void_p]
         L.mirt_intersect_count_dev.argtypes = L.mirt_intersect.argtypes + [C.POINTER(C.c_uint64),
                                                                           C.POINTER(C.c_uint64)]
+        L.mirt_intersect_audit_dev.argtypes = L.mirt_intersect.argtypes + [C.POINTER(C.c_uint64 * 5)]
         L.mirt_generate_rays_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32,
                                              C.c_void_p, C.c_void_p]
         L.mirt_render_pt.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
@@ -281,6 +282,13 @@ class Device:
         self._check(lib().mirt_intersect_count_dev(self.ctx, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr,
                                                    C.byref(nb), C.byref(nt)))
         return nb.value, nt.value
+
+    def intersect_audit_dev(self, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr):
+        """dict(box, tri, ambiguous, mismatch, walks) of the instrumented kernel"""
+        a = (C.c_uint64 * 5)()
+        self._check(lib().mirt_intersect_audit_dev(self.ctx, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr,
+                                                   C.byref(a)))
+        return dict(box=a[0], tri=a[1], ambiguous=a[2], mismatch=a[3], walks=a[4])
 
     def generate_rays_dev(self, cam, spp_begin, spp_count, seed, o_ptr, d_ptr):
         self._check(lib().mirt_generate_rays_dev(self.ctx, C.byref(cam), spp_begin, spp_count, seed, o_ptr, d_ptr))

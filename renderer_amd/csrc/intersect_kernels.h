@@ -19,6 +19,13 @@
 //     out of nodes), then all lanes test their leaf's triangles together. Leaves are no longer
 //     processed in the same iteration as other lanes' inner nodes, where they kept ~10 % of the lanes
 //     busy for most of the time.
+//   * node boxes are decided by the slab classifier of mirt_dev.h (no divisions; ~4x fewer
+//     instructions than the reference's six-plane test) whenever that decision is provably the
+//     reference's; a box it cannot prove is entered anyway and marks the path "ambiguous"; a
+//     triangle accepted under such a path is first confirmed by the exact reference box test on every
+//     ancestor. Rays outside the classifier's error model (zero / extreme components) use the exact
+//     test throughout. The instrumented instantiation (COUNT) also runs the exact test beside every
+//     proven decision and counts disagreements (must be 0; tests/test_gpu_intersect.py).
 #pragma once
 #include "mirt_dev.h"
 
@@ -58,6 +65,33 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     int best_slot = -1;
     int sp = 0;
     int cur = -1, c0 = 0, c1 = 0;  // current node and its child / leaf words; cur < 0: no node left
+    bool amb = false;              // the path to `cur` holds a box the classifier could not prove
+    RayPre pre;
+    pre.inv = mk3(0, 0, 0);
+    pre.a_ray = 0.f;
+    pre.fast = false;
+    unsigned long long c_amb = 0, c_bad = 0, c_walk = 0;
+
+    // one node box: hit / entry distance / "unproven" flag
+    auto test_box = [&](const NodeRec& r, bool& hit, float& lb, bool& unproven) {
+        if (pre.fast) {
+            const int code = slab_classify(r.lo, r.hi, o, pre, lb);
+            hit = code != BOX_MISS;
+            unproven = code == BOX_AMBIGUOUS;
+            if (COUNT) {
+                if (unproven) {
+                    c_amb++;
+                } else if (box_test(r.lo, r.hi, o, d).hit != hit) {
+                    c_bad++;
+                }
+            }
+        } else {
+            const BoxHit b = box_test(r.lo, r.hi, o, d);
+            hit = b.hit;
+            lb = b.lb;
+            unproven = false;
+        }
+    };
 
     // next node from the stack (entries whose box starts beyond the closest hit are dropped)
     auto pop = [&]() {
@@ -66,7 +100,9 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             sp--;
             const float lb = stk_lb[sp * bs];
             if (prune(lb, best_slot >= 0, best)) continue;
-            cur = (int)stk_node[sp * bs];
+            const uint32_t w = stk_node[sp * bs];
+            cur = (int)(w & 0x7FFFFFFFu);
+            amb = (w >> 31) != 0;
             const NodeRec r = sc.nodes[cur];
             c0 = __float_as_int(r.lo.w);
             c1 = __float_as_int(r.hi.w);
@@ -105,10 +141,15 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 best = -1.f;
                 best_slot = -1;
                 sp = 0;
+                pre = ray_prepare(sc, o, d);
                 const NodeRec r = sc.nodes[0];
                 if (COUNT) c_box++;
-                if (box_test(r.lo, r.hi, o, d).hit) {
+                bool rh, ru;
+                float rlb;
+                test_box(r, rh, rlb, ru);
+                if (rh) {
                     cur = 0;
+                    amb = ru;
                     c0 = __float_as_int(r.lo.w);
                     c1 = __float_as_int(r.hi.w);
                 } else {
@@ -129,25 +170,33 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             const NodeRec rl = sc.nodes[left];
             const NodeRec rr = sc.nodes[right];
             if (COUNT) c_box += 2;
-            const BoxHit bl = box_test(rl.lo, rl.hi, o, d);
-            const BoxHit br = box_test(rr.lo, rr.hi, o, d);
+            bool hl, hr, ul, ur;
+            float lbl, lbr;
+            test_box(rl, hl, lbl, ul);
+            test_box(rr, hr, lbr, ur);
             const bool have = best_slot >= 0;
-            const bool hl = bl.hit && !prune(bl.lb, have, best);
-            const bool hr = br.hit && !prune(br.lb, have, best);
+            hl = hl && !prune(lbl, have, best);
+            hr = hr && !prune(lbr, have, best);
+            ul |= amb;
+            ur |= amb;
             if (hl && hr) {
-                const bool left_first = bl.lb <= br.lb;
-                stk_node[sp * bs] = left_first ? (uint32_t)right : (uint32_t)left;
-                stk_lb[sp * bs] = left_first ? br.lb : bl.lb;
+                const bool left_first = lbl <= lbr;
+                stk_node[sp * bs] = (left_first ? (uint32_t)right : (uint32_t)left) |
+                                    ((left_first ? ur : ul) ? 0x80000000u : 0u);
+                stk_lb[sp * bs] = left_first ? lbr : lbl;
                 sp++;
                 cur = left_first ? left : right;
+                amb = left_first ? ul : ur;
                 c0 = __float_as_int(left_first ? rl.lo.w : rr.lo.w);
                 c1 = __float_as_int(left_first ? rl.hi.w : rr.hi.w);
             } else if (hl) {
                 cur = left;
+                amb = ul;
                 c0 = __float_as_int(rl.lo.w);
                 c1 = __float_as_int(rl.hi.w);
             } else if (hr) {
                 cur = right;
+                amb = ur;
                 c0 = __float_as_int(rr.lo.w);
                 c1 = __float_as_int(rr.hi.w);
             } else {
@@ -174,6 +223,17 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                     const f3 nn = world_normal(T, V, sc.objects[hobj].has_vn != 0, pos);
                     if (!legal_noself(dot3(d, nn), hobj, contact, inside)) continue;
                 }
+                if (amb) {
+                    // an unproven box lies on the way here: the reference reaches this triangle only if
+                    // its own box test passes on every ancestor (KDTree.cpp:297)
+                    if (COUNT) c_walk++;
+                    bool ok = true;
+                    for (int nd = cur; nd >= 0 && ok; nd = sc.parents[nd]) {
+                        const NodeRec r = sc.nodes[nd];
+                        ok = box_test(r.lo, r.hi, o, d).hit;
+                    }
+                    if (!ok) continue;
+                }
                 best = t;
                 best_slot = s;
             }
@@ -196,10 +256,16 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         for (int off = 32; off > 0; off >>= 1) {
             c_box += __shfl_down(c_box, off);
             c_tri += __shfl_down(c_tri, off);
+            c_amb += __shfl_down(c_amb, off);
+            c_bad += __shfl_down(c_bad, off);
+            c_walk += __shfl_down(c_walk, off);
         }
         if (lane == 0) {
             atomicAdd(&counters[0], c_box);
             atomicAdd(&counters[1], c_tri);
+            atomicAdd(&counters[2], c_amb);
+            atomicAdd(&counters[3], c_bad);
+            atomicAdd(&counters[4], c_walk);
         }
     }
 }

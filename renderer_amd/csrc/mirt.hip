@@ -28,6 +28,7 @@ struct MirtContext {
     TriRec* d_tris = nullptr;
     VnRec* d_vns = nullptr;
     DevObject* d_objs = nullptr;
+    int* d_parents = nullptr;
     DevScene sc{};
     bool has_scene = false;
     bool has_unsupported = false;  // scene holds an object kind the shade kernel cannot scatter yet
@@ -39,7 +40,7 @@ struct MirtContext {
     float* d_L = nullptr;
     uint32_t* d_cnt = nullptr;   // [2] live-path counters (ping-pong)
     uint32_t* h_cnt = nullptr;   // pinned
-    unsigned long long* d_counters = nullptr;  // [2] box / triangle test counters
+    unsigned long long* d_counters = nullptr;  // [8] audit counters of the instrumented kernel
     uint32_t* d_queue = nullptr;               // ray queue head of the persistent intersect kernel
     int n_cus = 256;
     int max_blocks = 1024;                     // resident blocks of the intersect kernel (grid cap)
@@ -134,7 +135,7 @@ int mirt_create(int device, MirtContext** out) {
     }
     if ((e = hipMalloc(&ctx->d_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
         (e = hipHostMalloc(&ctx->h_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc(&ctx->d_counters, 2 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc(&ctx->d_queue, 64 * sizeof(uint32_t))) != hipSuccess) {
         g_create_err = std::string("mirt_create: ") + hipGetErrorString(e);
         delete ctx;
@@ -149,6 +150,8 @@ static void free_scene(MirtContext* ctx) {
     hipFree(ctx->d_tris);
     hipFree(ctx->d_vns);
     hipFree(ctx->d_objs);
+    hipFree(ctx->d_parents);
+    ctx->d_parents = nullptr;
     ctx->d_nodes = nullptr;
     ctx->d_tris = nullptr;
     ctx->d_vns = nullptr;
@@ -285,6 +288,22 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         nodes[i].lo = make_float4(s->node_min[3 * i], s->node_min[3 * i + 1], s->node_min[3 * i + 2], f0);
         nodes[i].hi = make_float4(s->node_max[3 * i], s->node_max[3 * i + 1], s->node_max[3 * i + 2], f1);
     }
+    // parent links (ancestor-chain verification) and the facts the slab classifier's error model needs
+    std::vector<int> parents(N, -1);
+    for (int i = 0; i < N; i++)
+        if (s->node_right[i] >= 0) {
+            parents[i + 1] = i;
+            parents[s->node_right[i]] = i;
+        }
+    float bound[3] = {0.f, 0.f, 0.f};
+    int fast_ok = 1;
+    for (int i = 0; i < N; i++)
+        for (int c = 0; c < 3; c++)
+            for (float v : {s->node_min[3 * i + c], s->node_max[3 * i + c]}) {
+                float a = std::fabs(v);
+                if (!(a == 0.f || (a >= 1.4551915e-11f && a < 1.1529215e18f))) fast_ok = 0;  // also NaN/inf
+                if (i == 0 && a > bound[c]) bound[c] = a;
+            }
     std::vector<TriRec> tris(T);
     std::vector<VnRec> vns(T);
     for (int k = 0; k < T; k++) {
@@ -332,6 +351,11 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     HIPCHK(ctx, hipMemcpy(ctx->d_tris, tris.data(), sizeof(TriRec) * (size_t)T, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->d_vns, vns.data(), sizeof(VnRec) * (size_t)T, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->d_objs, objs.data(), sizeof(DevObject) * (size_t)s->n_objects, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc(&ctx->d_parents, sizeof(int) * (size_t)N));
+    HIPCHK(ctx, hipMemcpy(ctx->d_parents, parents.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice));
+    ctx->sc.parents = ctx->d_parents;
+    for (int c = 0; c < 3; c++) ctx->sc.bound[c] = bound[c];
+    ctx->sc.fast_ok = fast_ok;
     ctx->sc.nodes = ctx->d_nodes;
     ctx->sc.tris = ctx->d_tris;
     ctx->sc.vns = ctx->d_vns;
@@ -412,25 +436,37 @@ int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* dire
                                           (uint32_t)n, t_out, tid_out);
 }
 
-int mirt_intersect_count_dev(MirtContext* ctx, const float* origins, const float* directions,
+int mirt_intersect_audit_dev(MirtContext* ctx, const float* origins, const float* directions,
                              const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
-                             uint64_t* n_box_tests, uint64_t* n_tri_tests) {
+                             uint64_t audit[5]) {
     int rc = check_intersect_args(ctx, origins, directions, aux, n, mode, t_out, tid_out);
     if (rc != MIRT_OK) return rc;
-    if (!n_box_tests || !n_tri_tests) return fail(ctx, MIRT_E_INVALID, "intersect_count: NULL counter");
-    *n_box_tests = *n_tri_tests = 0;
+    if (!audit) return fail(ctx, MIRT_E_INVALID, "intersect_audit: NULL counter array");
+    for (int k = 0; k < 5; k++) audit[k] = 0;
     if (n == 0) return MIRT_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
     rc = launch_intersect<true, false>(ctx, ctx->stream, mode, origins, directions, aux,
                                        (uint32_t)n, (uint32_t)n, t_out, tid_out);
     if (rc != MIRT_OK) return rc;
-    unsigned long long h[2];
+    unsigned long long h[5];
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *n_box_tests = h[0];
-    *n_tri_tests = h[1];
+    for (int k = 0; k < 5; k++) audit[k] = h[k];
     return MIRT_OK;
+}
+
+int mirt_intersect_count_dev(MirtContext* ctx, const float* origins, const float* directions,
+                             const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
+                             uint64_t* n_box_tests, uint64_t* n_tri_tests) {
+    if (ctx && (!n_box_tests || !n_tri_tests)) return fail(ctx, MIRT_E_INVALID, "intersect_count: NULL counter");
+    uint64_t audit[5];
+    int rc = mirt_intersect_audit_dev(ctx, origins, directions, aux, n, mode, t_out, tid_out, audit);
+    if (rc == MIRT_OK) {
+        *n_box_tests = audit[0];
+        *n_tri_tests = audit[1];
+    }
+    return rc;
 }
 
 int mirt_intersect(MirtContext* ctx, const float* origins, const float* directions, const int32_t* aux,

@@ -47,7 +47,10 @@ struct DevScene {
     const TriRec* tris;
     const VnRec* vns;
     const DevObject* objects;
+    const int* parents;   // parent node index, -1 for the root (ancestor-chain verification)
     int n_nodes, n_tris, n_objects, depth;
+    float bound[3];       // max |coordinate| of the root box per axis
+    int fast_ok;          // every node bound is 0 or in [2^-36, 2^60): the slab classifier may be used
 };
 
 struct f3 {
@@ -129,6 +132,73 @@ __device__ __forceinline__ BoxHit box_test(const float4 lo, const float4 hi, f3 
         lb = nr > lb ? nr : lb;
     }
     return BoxHit{hit, lb};
+}
+
+// ---- slab classifier -------------------------------------------------------------------------
+// The reference box test costs six correctly rounded divisions and thirty compares. In exact
+// arithmetic it is the plain "ray meets closed box, t >= 0" predicate; in fp32 it can differ from
+// that only when two of the slab parameters (three entry values, three exit values) or an entry /
+// exit value and the box's other faces nearly coincide. slab_classify() evaluates the slab
+// parameters with per-ray reciprocals and returns
+//     BOX_MISS / BOX_HIT  when the reference's fp32 result is PROVABLY that (all deciding gaps
+//                         exceed the rounding bound M derived in DESIGN.md "slab classifier"),
+//     BOX_AMBIGUOUS       otherwise; the traversal then descends anyway and remembers that the path
+//                         holds an unproven box: a triangle found below it is accepted only after the
+//                         exact reference test has passed on every ancestor (rare).
+// Signs need no margin: t = RN(P - o) * y has exactly the sign of the reference's quotient.
+enum { BOX_MISS = 0, BOX_HIT = 1, BOX_AMBIGUOUS = 2 };
+
+struct RayPre {
+    f3 inv;       // RN(1/d) per axis
+    float a_ray;  // absolute part of the margin: 16 eps * max_a (|o_a| + bound_a) * |inv_a|
+    bool fast;    // the classifier's error model holds for this ray
+};
+
+__device__ __forceinline__ bool in_range(float v, float lo, float hi) {
+    float a = fabsf(v);
+    return a >= lo && a < hi;
+}
+
+__device__ __forceinline__ RayPre ray_prepare(const DevScene& sc, f3 o, f3 d) {
+    RayPre p;
+    const float lo_d = 9.094947e-13f /*2^-40*/, hi_d = 1.0995116e12f /*2^40*/;
+    const float lo_o = 1.4551915e-11f /*2^-36*/, hi_o = 1.1529215e18f /*2^60*/;
+    p.fast = sc.fast_ok != 0 && in_range(d.x, lo_d, hi_d) && in_range(d.y, lo_d, hi_d) &&
+             in_range(d.z, lo_d, hi_d) && (o.x == 0.f || in_range(o.x, lo_o, hi_o)) &&
+             (o.y == 0.f || in_range(o.y, lo_o, hi_o)) && (o.z == 0.f || in_range(o.z, lo_o, hi_o));
+    p.inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    float ax = (fabsf(o.x) + sc.bound[0]) * fabsf(p.inv.x);
+    float ay = (fabsf(o.y) + sc.bound[1]) * fabsf(p.inv.y);
+    float az = (fabsf(o.z) + sc.bound[2]) * fabsf(p.inv.z);
+    p.a_ray = 9.5367431640625e-07f /*16 * 2^-24*/ * fmaxf(ax, fmaxf(ay, az));
+    return p;
+}
+
+__device__ __forceinline__ int slab_classify(const float4 lo, const float4 hi, f3 o, const RayPre& p,
+                                             float& lb) {
+    const float t0x = (lo.x - o.x) * p.inv.x, t1x = (hi.x - o.x) * p.inv.x;
+    const float t0y = (lo.y - o.y) * p.inv.y, t1y = (hi.y - o.y) * p.inv.y;
+    const float t0z = (lo.z - o.z) * p.inv.z, t1z = (hi.z - o.z) * p.inv.z;
+    const float nx = fminf(t0x, t1x), fx = fmaxf(t0x, t1x);
+    const float ny = fminf(t0y, t1y), fy = fmaxf(t0y, t1y);
+    const float nz = fminf(t0z, t1z), fz = fmaxf(t0z, t1z);
+    const float tn = fmaxf(nx, fmaxf(ny, nz)), n2 = __builtin_amdgcn_fmed3f(nx, ny, nz);
+    const float tf = fminf(fx, fminf(fy, fz)), f2 = __builtin_amdgcn_fmed3f(fx, fy, fz);
+    const float M = p.a_ray + 1.9073486e-06f /*32 * 2^-24*/ * (fabsf(tn) + fabsf(tf));
+    const float gap = tf - tn;
+    const bool sep_top = tn - n2 > M, sep_bot = f2 - tf > M;
+    lb = fmaxf(tn, 0.f);
+    bool ok_gap = gap > M, behind_flat = false;
+    if (!ok_gap && gap >= 0.f) {
+        // entry and exit value of the SAME axis (a thin or flat box, e.g. an axis-aligned wall): the
+        // two never cross, so only the separation from the other axes matters
+        const bool same = ((nx == tn) & (fx == tf)) | ((ny == tn) & (fy == tf)) | ((nz == tn) & (fz == tf));
+        ok_gap = same;
+        behind_flat = same & (tn == tf) & (tf < 0.f);  // a flat box behind the origin (sign is exact)
+    }
+    if (ok_gap && ((tf >= 0.f && sep_bot) || (tn >= 0.f && sep_top))) return BOX_HIT;
+    if (tf < -M || (-gap > M && sep_top && sep_bot) || behind_flat) return BOX_MISS;
+    return BOX_AMBIGUOUS;
 }
 
 // a subtree whose box starts beyond the closest accepted hit cannot change the result; the slack

@@ -118,8 +118,10 @@ def test_large_batch_properties(cornell_dev, cornell, ra):
 
 
 def test_counts_match_ordered_restatement(cornell_dev, cornell, cornell_oracle, ra):
-    """The instrumented kernel's box / triangle test counts equal the CPU restatement of the same
-    traversal order (they feed the algorithmic-bytes figure of bench.py)."""
+    """The instrumented kernel's box / triangle test counts agree with the CPU restatement of the
+    same traversal order (they feed the algorithmic-bytes figure of bench.py). Not bit-equal: the
+    kernel orders children by slab distances computed with per-ray reciprocals and enters the rare
+    boxes its classifier cannot prove, so a few visits differ."""
     import torch
 
     n = 50000
@@ -132,10 +134,49 @@ def test_counts_match_ordered_restatement(cornell_dev, cornell, cornell_oracle, 
         nb, nt = cornell_dev.intersect_count_dev(to.data_ptr(), do_.data_ptr(), ta.data_ptr(), n, mode,
                                                  tt.data_ptr(), ti.data_ptr())
         t2, i2, cb, ct = cornell_oracle.intersect_ordered(o, d, aux, mode)
-        assert (nb, nt) == (cb, ct)
+        assert abs(nb - cb) / cb < 0.02 and abs(nt - ct) / ct < 0.02, (nb, cb, nt, ct)
         assert np.array_equal(ti.cpu().numpy(), i2) and np.array_equal(tt.cpu().numpy(), t2)
         rb, rt = cornell_oracle.ref_counts(o[:, :5000], d[:, :5000], aux[:5000], mode)
         assert nb / n < rb / 5000 and nt / n < rt / 5000
+
+
+def test_classifier_audit(gpu, cornell, mesh20k, cornell_oracle, ra):
+    """Every box decision the slab classifier claims to have PROVEN is re-evaluated with the exact
+    reference test inside the instrumented kernel: zero disagreements over millions of rays, incl.
+    rays that start on surfaces, axis-parallel rays (exact path) and near-axis-parallel rays."""
+    import torch
+
+    cam = cornell.camera()
+    surf = []
+    for pixel in range(0, 128 * 128, 2):
+        verts, _, nv = cornell_oracle.trace_path(cam, pixel, 3)
+        for k in range(1, min(nv, len(verts))):
+            if np.linalg.norm(verts[k][3:6]) > 0.5:
+                surf.append(verts[k][:6])
+    surf = np.array(surf, np.float32)
+    for scene, inside in ((cornell, 2), (mesh20k, 8)):
+        gpu.upload(scene.describe())
+        n = 1 << 21
+        o, d, aux = meshgen.random_rays(n, 91, scene.n_objects, inside_obj=inside)
+        # surface-origin rays with fresh random directions, near-axis-parallel and axis-parallel rays
+        k = len(surf)
+        o[:, :k] = surf[:, :3].T
+        rng = np.random.default_rng(5)
+        d[:, 2 * k:3 * k] *= np.array([[1.0], [1e-6], [1.0]], np.float32)
+        d[1, 3 * k:4 * k] = 0.0
+        d[:, 4 * k:5 * k] = surf[:, 3:6].T
+        o[:, 4 * k:5 * k] = surf[:, :3].T
+        d /= np.maximum(np.linalg.norm(d, axis=0, keepdims=True), 1e-30)
+        to, do_, ta = (torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (o, d.astype(np.float32), aux))
+        tt = torch.empty(n, dtype=torch.float32, device="cuda")
+        ti = torch.empty(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for mode in (0, 2):
+            a = gpu.intersect_audit_dev(to.data_ptr(), do_.data_ptr(), ta.data_ptr(), n, mode, tt.data_ptr(),
+                                        ti.data_ptr())
+            assert a["mismatch"] == 0, a
+            assert a["ambiguous"] / a["box"] < 0.10, a  # even on this adversarial mix most boxes are proven
+            assert a["walks"] / n < 0.25, a
 
 
 def test_device_pointer_entry_and_streams(cornell_dev, cornell, cornell_oracle, ra):
