@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmirt.so")
+LIB_PATH = os.environ.get("MIRT_LIB") or os.path.join(_HERE, "libmirt.so")  # MIRT_LIB: A/B builds
 REPO_ROOT = os.path.dirname(_HERE)
 DATA_DIR = os.path.join(REPO_ROOT, "Data")
 
@@ -93,7 +93,7 @@ def lib():
         L.mirt_intersect_dev.argtypes = L.mirt_intersect.argtypes + [C.c_void_p]
         L.mirt_intersect_count_dev.argtypes = L.mirt_intersect.argtypes + [C.POINTER(C.c_uint64),
                                                                           C.POINTER(C.c_uint64)]
-        L.mirt_intersect_audit_dev.argtypes = L.mirt_intersect.argtypes + [C.POINTER(C.c_uint64 * 5)]
+        L.mirt_intersect_audit_dev.argtypes = L.mirt_intersect.argtypes + [C.POINTER(C.c_uint64 * 8)]
         L.mirt_generate_rays_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32,
                                              C.c_void_p, C.c_void_p]
         L.mirt_render_pt.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
@@ -285,10 +285,11 @@ class Device:
 
     def intersect_audit_dev(self, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr):
         """dict(box, tri, ambiguous, mismatch, walks) of the instrumented kernel"""
-        a = (C.c_uint64 * 5)()
+        a = (C.c_uint64 * 8)()
         self._check(lib().mirt_intersect_audit_dev(self.ctx, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr,
                                                    C.byref(a)))
-        return dict(box=a[0], tri=a[1], ambiguous=a[2], mismatch=a[3], walks=a[4])
+        return dict(box=a[0], tri=a[1], ambiguous=a[2], mismatch=a[3], walks=a[4], wave_inner=a[5],
+                    wave_leaf=a[6], wave_outer=a[7])
 
     def generate_rays_dev(self, cam, spp_begin, spp_count, seed, o_ptr, d_ptr):
         self._check(lib().mirt_generate_rays_dev(self.ctx, C.byref(cam), spp_begin, spp_count, seed, o_ptr, d_ptr))

@@ -25,6 +25,7 @@ struct MirtContext {
     std::string info;
     // scene
     NodeRec* d_nodes = nullptr;
+    PairRec* d_pairs = nullptr;
     TriRec* d_tris = nullptr;
     VnRec* d_vns = nullptr;
     DevObject* d_objs = nullptr;
@@ -41,7 +42,9 @@ struct MirtContext {
     uint32_t* d_cnt = nullptr;   // [2] live-path counters (ping-pong)
     uint32_t* h_cnt = nullptr;   // pinned
     unsigned long long* d_counters = nullptr;  // [8] audit counters of the instrumented kernel
-    uint32_t* d_queue = nullptr;               // ray queue head of the persistent intersect kernel
+    uint32_t* d_queue = nullptr;               // [0] ray queue head, [1] deferred-ray count
+    uint32_t* d_defer = nullptr;               // indices of rays handed to the exact kernel
+    size_t defer_cap = 0;
     int n_cus = 256;
     int max_blocks = 1024;                     // resident blocks of the intersect kernel (grid cap)
     // staging for the host-pointer intersect
@@ -147,6 +150,8 @@ int mirt_create(int device, MirtContext** out) {
 
 static void free_scene(MirtContext* ctx) {
     hipFree(ctx->d_nodes);
+    hipFree(ctx->d_pairs);
+    ctx->d_pairs = nullptr;
     hipFree(ctx->d_tris);
     hipFree(ctx->d_vns);
     hipFree(ctx->d_objs);
@@ -190,6 +195,7 @@ int mirt_destroy(MirtContext* ctx) {
     hipFree(ctx->d_cnt);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_queue);
+    hipFree(ctx->d_defer);
     if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -304,6 +310,51 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
                 if (!(a == 0.f || (a >= 1.4551915e-11f && a < 1.1529215e18f))) fast_ok = 0;  // also NaN/inf
                 if (i == 0 && a > bound[c]) bound[c] = a;
             }
+    // breadth-first child pairs
+    if (T > (1 << 24)) return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: more than 2^24 triangles");
+    std::vector<int> slot_leaf(T, 0);
+    auto link_of_leaf = [&](int i, int* out) -> bool {
+        int b = s->node_leaf_begin[i], cnt = s->node_leaf_end[i] - b;
+        if (cnt > 127) return false;
+        for (int k = b; k < b + cnt; k++) slot_leaf[k] = i;
+        *out = ~(int)((uint32_t)b | ((uint32_t)cnt << 24));
+        return true;
+    };
+    std::vector<int> order;  // inner nodes in BFS order; pair id = position
+    std::vector<int> pair_of(N, -1);
+    if (s->node_right[0] >= 0) {
+        order.push_back(0);
+        pair_of[0] = 0;
+    }
+    for (size_t q = 0; q < order.size(); q++) {
+        int i = order[q];
+        for (int c : {i + 1, s->node_right[i]})
+            if (s->node_right[c] >= 0) {
+                pair_of[c] = (int)order.size();
+                order.push_back(c);
+            }
+    }
+    std::vector<PairRec> pairs(std::max<size_t>(order.size(), 1));
+    auto child_rec = [&](int c, float4* lo, float4* hi) -> bool {
+        int lk;
+        if (s->node_right[c] >= 0) lk = pair_of[c];
+        else if (!link_of_leaf(c, &lk)) return false;
+        float fl, fn;
+        memcpy(&fl, &lk, 4);
+        memcpy(&fn, &c, 4);
+        *lo = make_float4(s->node_min[3 * c], s->node_min[3 * c + 1], s->node_min[3 * c + 2], fl);
+        *hi = make_float4(s->node_max[3 * c], s->node_max[3 * c + 1], s->node_max[3 * c + 2], fn);
+        return true;
+    };
+    memset(pairs.data(), 0, sizeof(PairRec) * pairs.size());
+    for (size_t q = 0; q < order.size(); q++) {
+        int i = order[q];
+        if (!child_rec(i + 1, &pairs[q].llo, &pairs[q].lhi) || !child_rec(s->node_right[i], &pairs[q].rlo, &pairs[q].rhi))
+            return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: a leaf holds more than 127 triangles");
+    }
+    float4 root_lo, root_hi;
+    if (!child_rec(0, &root_lo, &root_hi))
+        return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: a leaf holds more than 127 triangles");
     std::vector<TriRec> tris(T);
     std::vector<VnRec> vns(T);
     for (int k = 0; k < T; k++) {
@@ -322,7 +373,9 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         const float* vn = s->tri_vn ? s->tri_vn + 9 * (size_t)g : nullptr;
         vns[k].n0 = make_float4(vn ? vn[0] : 0.f, vn ? vn[1] : 0.f, vn ? vn[2] : 0.f, fo);
         vns[k].n1 = make_float4(vn ? vn[3] : 0.f, vn ? vn[4] : 0.f, vn ? vn[5] : 0.f, fg);
-        vns[k].n2 = make_float4(vn ? vn[6] : 0.f, vn ? vn[7] : 0.f, vn ? vn[8] : 0.f, 0.f);
+        float fl;
+        memcpy(&fl, &slot_leaf[k], 4);
+        vns[k].n2 = make_float4(vn ? vn[6] : 0.f, vn ? vn[7] : 0.f, vn ? vn[8] : 0.f, fl);
     }
     std::vector<DevObject> objs(s->n_objects);
     for (int o = 0; o < s->n_objects; o++) {
@@ -344,6 +397,8 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
     HIPCHK(ctx, hipMalloc(&ctx->d_nodes, sizeof(NodeRec) * (size_t)N));
+    HIPCHK(ctx, hipMalloc(&ctx->d_pairs, sizeof(PairRec) * pairs.size()));
+    HIPCHK(ctx, hipMemcpy(ctx->d_pairs, pairs.data(), sizeof(PairRec) * pairs.size(), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMalloc(&ctx->d_tris, sizeof(TriRec) * (size_t)T));
     HIPCHK(ctx, hipMalloc(&ctx->d_vns, sizeof(VnRec) * (size_t)T));
     HIPCHK(ctx, hipMalloc(&ctx->d_objs, sizeof(DevObject) * (size_t)s->n_objects));
@@ -357,6 +412,9 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     for (int c = 0; c < 3; c++) ctx->sc.bound[c] = bound[c];
     ctx->sc.fast_ok = fast_ok;
     ctx->sc.nodes = ctx->d_nodes;
+    ctx->sc.pairs = ctx->d_pairs;
+    ctx->sc.root_lo = root_lo;
+    ctx->sc.root_hi = root_hi;
     ctx->sc.tris = ctx->d_tris;
     ctx->sc.vns = ctx->d_vns;
     ctx->sc.objects = ctx->d_objs;
@@ -382,27 +440,42 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
 }  // extern "C"
 
 // ---- launches -------------------------------------------------------------------------------------
+template <int MODE, bool COUNT, bool SLOT_OUT>
+static void launch_pair(MirtContext* ctx, hipStream_t st, dim3 grid, dim3 block, const float* O, const float* D,
+                        const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out) {
+    hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT>), grid, block, ctx->lds, st, ctx->sc, O, D, aux, n,
+                       stride, t_out, id_out, ctx->d_counters, ctx->d_queue, ctx->d_defer);
+    // the deferred rays (usually a handful): exact reference box test throughout
+    hipLaunchKernelGGL((k_intersect_exact<MODE, COUNT, SLOT_OUT>), dim3(std::min<uint32_t>(grid.x, 64)), block,
+                       ctx->lds, st, ctx->sc, O, D, aux, stride, t_out, id_out, ctx->d_counters, ctx->d_defer,
+                       ctx->d_queue + 1);
+}
+
 template <bool COUNT, bool SLOT_OUT>
 static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
                             const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out) {
     if (n == 0) return MIRT_OK;
+    if (n > ctx->defer_cap) {  // grows only when a larger batch than ever before arrives
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        hipFree(ctx->d_defer);
+        ctx->d_defer = nullptr;
+        ctx->defer_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_defer, sizeof(uint32_t) * (size_t)n));
+        ctx->defer_cap = n;
+    }
     const uint32_t want = (n + ctx->block - 1) / ctx->block;
     dim3 block(ctx->block), grid(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks));
-    unsigned long long* cnt = ctx->d_counters;
-    // the ray queue head must start at zero for every launch
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), st));
+    // queue head and deferred-ray count start at zero for every launch
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(uint32_t), st));
     switch (mode) {
         case MIRT_MODE_UNCONDITIONAL:
-            hipLaunchKernelGGL((k_intersect<MIRT_MODE_UNCONDITIONAL, COUNT, SLOT_OUT>), grid, block,
-                               ctx->lds, st, ctx->sc, O, D, aux, n, stride, t_out, id_out, cnt, ctx->d_queue);
+            launch_pair<MIRT_MODE_UNCONDITIONAL, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, stride, t_out, id_out);
             break;
         case MIRT_MODE_LAST_TID:
-            hipLaunchKernelGGL((k_intersect<MIRT_MODE_LAST_TID, COUNT, SLOT_OUT>), grid, block,
-                               ctx->lds, st, ctx->sc, O, D, aux, n, stride, t_out, id_out, cnt, ctx->d_queue);
+            launch_pair<MIRT_MODE_LAST_TID, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, stride, t_out, id_out);
             break;
         case MIRT_MODE_NO_SELF:
-            hipLaunchKernelGGL((k_intersect<MIRT_MODE_NO_SELF, COUNT, SLOT_OUT>), grid, block,
-                               ctx->lds, st, ctx->sc, O, D, aux, n, stride, t_out, id_out, cnt, ctx->d_queue);
+            launch_pair<MIRT_MODE_NO_SELF, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, stride, t_out, id_out);
             break;
         default:
             return fail(ctx, MIRT_E_INVALID, "intersect: unknown mode");
@@ -438,21 +511,21 @@ int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* dire
 
 int mirt_intersect_audit_dev(MirtContext* ctx, const float* origins, const float* directions,
                              const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
-                             uint64_t audit[5]) {
+                             uint64_t audit[8]) {
     int rc = check_intersect_args(ctx, origins, directions, aux, n, mode, t_out, tid_out);
     if (rc != MIRT_OK) return rc;
     if (!audit) return fail(ctx, MIRT_E_INVALID, "intersect_audit: NULL counter array");
-    for (int k = 0; k < 5; k++) audit[k] = 0;
+    for (int k = 0; k < 8; k++) audit[k] = 0;
     if (n == 0) return MIRT_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
     rc = launch_intersect<true, false>(ctx, ctx->stream, mode, origins, directions, aux,
                                        (uint32_t)n, (uint32_t)n, t_out, tid_out);
     if (rc != MIRT_OK) return rc;
-    unsigned long long h[5];
+    unsigned long long h[8];
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 5; k++) audit[k] = h[k];
+    for (int k = 0; k < 8; k++) audit[k] = h[k];
     return MIRT_OK;
 }
 
@@ -460,7 +533,7 @@ int mirt_intersect_count_dev(MirtContext* ctx, const float* origins, const float
                              const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
                              uint64_t* n_box_tests, uint64_t* n_tri_tests) {
     if (ctx && (!n_box_tests || !n_tri_tests)) return fail(ctx, MIRT_E_INVALID, "intersect_count: NULL counter");
-    uint64_t audit[5];
+    uint64_t audit[8];
     int rc = mirt_intersect_audit_dev(ctx, origins, directions, aux, n, mode, t_out, tid_out, audit);
     if (rc == MIRT_OK) {
         *n_box_tests = audit[0];

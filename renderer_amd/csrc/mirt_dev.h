@@ -22,6 +22,13 @@ namespace mirt {
 struct NodeRec {
     float4 lo, hi;
 };
+// traversal record, 64 B: the two children of one inner node, in BREADTH-FIRST order of the inner
+// nodes (the top of the tree is contiguous). Per child: (min.xyz, bits link), (max.xyz, bits node id)
+//   link >= 0: index of the child's own PairRec (inner node)
+//   link <  0: leaf, ~link = first slot | (triangle count << 24)
+struct PairRec {
+    float4 llo, lhi, rlo, rhi;
+};
 // triangle record in SLOT (leaf) order, 48 B: positions + the unit plane normal the reference
 // recomputes per test (KDTree.cpp:283-284), precomputed on the host with identical arithmetic.
 //   a = (v0, n.x)  b = (v1, n.y)  c = (v2, n.z)
@@ -31,7 +38,7 @@ struct TriRec {
 // per-slot shading data, 48 B, touched only for candidate hits that would win (predicate) and in
 // the shade kernel: corner normals (normal-matrix transformed, not normalised).
 struct VnRec {
-    float4 n0, n1, n2;  // .w of n0 = bits(object id), n1.w = bits(global tid), n2.w unused
+    float4 n0, n1, n2;  // .w: n0 bits(object id), n1 bits(global tid), n2 bits(pre-order id of the leaf)
 };
 
 struct DevObject {
@@ -43,7 +50,9 @@ struct DevObject {
 };
 
 struct DevScene {
-    const NodeRec* nodes;
+    const NodeRec* nodes;  // pre-order records: exact-path traversal and ancestor verification
+    const PairRec* pairs;  // breadth-first child pairs: the classifier-path traversal
+    float4 root_lo, root_hi;  // root box; root_lo.w = bits(link of the root)
     const TriRec* tris;
     const VnRec* vns;
     const DevObject* objects;
