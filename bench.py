@@ -182,7 +182,7 @@ def main():
                 "tri_tests_per_ray": round((ptr_ + str_) / n_rays, 3),
                 "classifier": {"unproven_box_fraction": round((pa["ambiguous"] + sa_["ambiguous"]) / (pb + sb), 5),
                                "proven_decisions_disagreeing_with_exact_test": pa["mismatch"] + sa_["mismatch"],
-                               "chain_verifications_per_ray": round((pa["walks"] + sa_["walks"]) / n_rays, 5)},
+                               "exact_box_tests_per_ray": round((pa["walks"] + sa_["walks"]) / n_rays, 5)},
                 "parallelism": "ray-sharded x%d, no collective" % world,
             },
         }

@@ -154,8 +154,8 @@ int mirt_intersect_count_dev(MirtContext* ctx, const float* origins, const float
 
 /* Full audit of the same instrumented run: audit[0] node-box tests, [1] triangle tests, [2] boxes the
  * slab classifier could not prove (entered and flagged), [3] proven decisions that DISAGREE with the
- * exact reference box test evaluated beside them (must be 0), [4] rays re-traced by the exact kernel
- * because their closest hit rested on an unproven box, [5] whole-wave inner steps, [6] whole-wave
+ * exact reference box test evaluated beside them (must be 0), [4] boxes decided by the reference arithmetic
+ * (the unproven ones plus every box of rays outside the classifier's model), [5] whole-wave inner steps, [6] whole-wave
  * triangle iterations, [7] whole-wave outer iterations (lane-utilisation diagnostics).              */
 int mirt_intersect_audit_dev(MirtContext* ctx, const float* origins, const float* directions,
                              const int32_t* aux, size_t n, int mode, float* t_out,

@@ -20,13 +20,13 @@
 //   * one 64-byte PairRec load per inner step brings both children's boxes and links (breadth-first
 //     pair order: the top of the tree is contiguous and stays in L1);
 //   * node boxes are decided by the slab classifier of mirt_dev.h (no divisions) whenever that
-//     decision is provably the reference's; a box it cannot prove is entered anyway and marks the
-//     path "ambiguous"; if a triangle under such a path would become the closest hit, the ray is
-//     handed to k_intersect_exact (a second, small launch that traces the deferred rays with the
-//     exact reference box test throughout; ~3e-5 of the rays on the Cornell batch). Rays outside the
-//     classifier's error model (zero / extreme components) are deferred the same way.
+//     decision is provably the reference's; a box it cannot prove (~8e-5 of the tests on the Cornell
+//     batch) and every box of a ray outside its error model (zero / extreme components) is decided by
+//     the reference arithmetic itself, in a branch whole waves normally skip.
 //     The instrumented instantiation (COUNT) also runs the exact test beside every proven decision
-//     and counts disagreements (must be 0; tests/test_gpu_intersect.py).
+//     and counts disagreements (must be 0; tests/test_gpu_intersect.py);
+//   * in NO_SELF mode the predicate (shading normal, ~300 instructions for smooth-shaded objects) is
+//     evaluated once per leaf pass for all lanes that found a candidate, not inside the triangle loop.
 #pragma once
 #include "mirt_dev.h"
 
@@ -57,124 +57,31 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
         const VnRec V = sc.vns[s];
         const int hobj = __float_as_int(V.n0.w);
         const f3 pos = o + d * t;
-        const f3 nn = world_normal(T, V, sc.objects[hobj].has_vn != 0, pos);
+        const f3 nn = world_normal(T, V, __float_as_int(V.n2.w) != 0, pos);
         return legal_noself(dot3(d, nn), hobj, contact, inside);
     }
     return true;
 }
 
-// Traces the deferred rays (indices in `list`, count in *list_n) with the exact reference box test
-// throughout: pre-order node records, same ordering / pruning / tie rules as the main kernel.
-template <int MODE, bool COUNT, bool SLOT_OUT>
-__global__ void __launch_bounds__(256)
-k_intersect_exact(DevScene sc, const float* __restrict__ O, const float* __restrict__ D,
-                  const int* __restrict__ aux, uint32_t plane_stride, float* __restrict__ t_out,
-                  int* __restrict__ id_out, unsigned long long* __restrict__ counters,
-                  const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n) {
-    extern __shared__ uint32_t lds[];
-    const uint32_t bs = blockDim.x;
-    uint32_t* stk_node = lds + threadIdx.x;
-    float* stk_lb = (float*)(lds + (sc.depth + 1) * bs) + threadIdx.x;
-    const uint32_t count = *list_n;
-    Audit au;
-    for (uint32_t k = blockIdx.x * bs + threadIdx.x; k < count; k += gridDim.x * bs) {
-        const uint32_t idx = list[k];
-        const f3 o = mk3(O[idx], O[plane_stride + idx], O[2 * plane_stride + idx]);
-        const f3 d = mk3(D[idx], D[plane_stride + idx], D[2 * plane_stride + idx]);
-        int a = 0;
-        if (MODE != MIRT_MODE_UNCONDITIONAL) a = aux[idx];
-        const int contact = unpack_contact(a), inside = unpack_inside(a);
-        float best = -1.f;
-        int best_slot = -1, sp = 0, cur = -1;
-        {
-            const NodeRec r = sc.nodes[0];
-            if (COUNT) au.box++;
-            if (box_test(r.lo, r.hi, o, d).hit) cur = 0;
-        }
-        while (cur >= 0) {
-            const NodeRec r = sc.nodes[cur];
-            const int c0 = __float_as_int(r.lo.w);
-            bool pop = false;
-            if (c0 < 0) {
-                const int lbeg = ~c0, lend = __float_as_int(r.hi.w);
-                for (int s = lbeg; s < lend; s++) {
-                    const TriRec T = sc.tris[s];
-                    if (COUNT) au.tri++;
-                    const float t = tri_test(T, o, d);
-                    if (!(t >= 0.f)) continue;
-                    if (!(best_slot < 0 || t < best || (t == best && best_slot < lbeg))) continue;
-                    if (!candidate_legal<MODE>(sc, T, s, o, d, t, a, contact, inside)) continue;
-                    best = t;
-                    best_slot = s;
-                }
-                pop = true;
-            } else {
-                const NodeRec rl = sc.nodes[cur + 1];
-                const NodeRec rr = sc.nodes[c0];
-                if (COUNT) au.box += 2;
-                const BoxHit bl = box_test(rl.lo, rl.hi, o, d);
-                const BoxHit br = box_test(rr.lo, rr.hi, o, d);
-                const bool have = best_slot >= 0;
-                const bool hl = bl.hit && !prune(bl.lb, have, best);
-                const bool hr = br.hit && !prune(br.lb, have, best);
-                if (hl && hr) {
-                    const bool lf = bl.lb <= br.lb;
-                    stk_node[sp * bs] = lf ? (uint32_t)c0 : (uint32_t)(cur + 1);
-                    stk_lb[sp * bs] = lf ? br.lb : bl.lb;
-                    sp++;
-                    cur = lf ? cur + 1 : c0;
-                } else if (hl) {
-                    cur = cur + 1;
-                } else if (hr) {
-                    cur = c0;
-                } else {
-                    pop = true;
-                }
-            }
-            if (pop) {
-                cur = -1;
-                while (sp > 0) {
-                    sp--;
-                    if (prune(stk_lb[sp * bs], best_slot >= 0, best)) continue;
-                    cur = (int)stk_node[sp * bs];
-                    break;
-                }
-            }
-        }
-        t_out[idx] = best_slot >= 0 ? best : -1.f;
-        if (SLOT_OUT)
-            id_out[idx] = best_slot;
-        else
-            id_out[idx] = best_slot >= 0 ? __float_as_int(sc.vns[best_slot].n1.w) : -1;
-    }
-    if (COUNT) {
-        for (int off = 32; off > 0; off >>= 1) {
-            au.box += __shfl_down(au.box, off);
-            au.tri += __shfl_down(au.tri, off);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&counters[0], au.box);
-            atomicAdd(&counters[1], au.tri);
-        }
-    }
-}
-
 // MODE: MIRT_MODE_*   COUNT: audit counters (never timed)   SLOT_OUT: write the slot index (internal
 // path-tracing use) instead of the global triangle id.
-// `queue`: two zero-initialised words per launch: [0] index of the next unassigned ray, [1] number
-// of rays deferred to k_intersect_exact (their indices go to `defer`, capacity n).
+// `queue`: one zero-initialised word per launch, the index of the next unassigned ray.
 template <int MODE, bool COUNT, bool SLOT_OUT>
 __global__ void __launch_bounds__(256)
 k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ D,
             const int* __restrict__ aux, uint32_t n, uint32_t plane_stride, float* __restrict__ t_out,
             int* __restrict__ id_out, unsigned long long* __restrict__ counters,
-            uint32_t* __restrict__ queue, uint32_t* __restrict__ defer) {
+            uint32_t* __restrict__ queue, uint32_t lds_levels, uint2* __restrict__ spill) {
     extern __shared__ uint32_t lds[];
     const uint32_t bs = blockDim.x;
-    uint32_t* stk_node = lds + threadIdx.x;  // [level * bs]: child link
-    float* stk_lb = (float*)(lds + (sc.depth + 1) * bs) + threadIdx.x;  // entry distance | amb << 31
+    // per-lane stack, [level][lane] of (child link, entry distance): the first
+    // lds_levels levels in LDS, deeper ones (rarely reached) in the global spill area
+    uint2* stk = (uint2*)lds + threadIdx.x;
+    uint2* stk_deep = spill + ((size_t)blockIdx.x * bs + threadIdx.x);
+    const size_t deep_stride = (size_t)gridDim.x * bs;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const float INF = __builtin_inff();
 
     Audit au;
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform ray pool
@@ -182,49 +89,56 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
 
     // per-lane traversal state. `link` is the current child link: >= 0 pair index (inner node),
     // < 0 leaf (~link = begin | count << 24); has = false: nothing left to visit.
-    bool active = false, has = false, amb = false;
+    bool active = false, has = false;
     uint32_t idx = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
-    int a = 0, contact = -1, inside = -1;
-    float best = -1.f;
+    int a = 0;
+    float best = -1.f, thr = INF;  // thr: entry distances beyond it cannot beat the closest hit (prune())
     int best_slot = -1, sp = 0, link = 0;
-    int leaf_pos = 0, leaf_end = 0, leaf_beg = 0;  // triangles still to test in the current leaf
+    int leaf_pos = 0, leaf_end = 0;  // triangles still to test in the current leaf
     RayPre pre;
     pre.inv = mk3(0, 0, 0);
     pre.a_ray = 0.f;
     pre.fast = false;
 
-    auto classify = [&](const float4 lo, const float4 hi, float& lb, bool& unproven) -> bool {
-        const int code = slab_classify(lo, hi, o, pre, lb);
-        unproven = code == BOX_AMBIGUOUS;
-        if (COUNT) {
-            au.box++;
-            if (unproven)
-                au.amb++;
-            else if (box_test(lo, hi, o, d).hit != (code == BOX_HIT))
-                au.bad++;
+    // does the box pass the reference test? Decided by the slab classifier when it can prove the
+    // answer, by the reference arithmetic itself (box_test) otherwise: rarely taken, so whole waves
+    // skip it. Rays outside the classifier's error model (pre.fast false) always take the exact test.
+    auto resolve = [&](const float4 lo, const float4 hi, int code, float& lb) -> bool {
+        if (COUNT) au.box++;
+        if (!pre.fast || code == BOX_AMBIGUOUS) {
+            if (COUNT) {
+                au.walk++;
+                if (pre.fast) au.amb++;
+            }
+            const BoxHit b = box_test(lo, hi, o, d);
+            lb = b.lb;
+            return b.hit;
         }
-        return code != BOX_MISS;
+        if (COUNT && box_test(lo, hi, o, d).hit != (code == BOX_HIT)) au.bad++;
+        return code == BOX_HIT;
     };
     auto enter = [&](int lk) {  // start visiting child link lk
         link = lk;
         has = true;
-        if (lk < 0) {
-            const uint32_t v = (uint32_t)~lk;
-            leaf_beg = leaf_pos = (int)(v & 0xFFFFFFu);
-            leaf_end = leaf_pos + (int)(v >> 24);
-        }
+        const uint32_t v = ~(uint32_t)lk;  // leaf fields; meaningless (and unused) for an inner node
+        leaf_pos = (int)(v & 0xFFFFFFu);
+        leaf_end = leaf_pos + (int)(v >> 24);
     };
     auto pop = [&]() {  // next node from the stack; entries beyond the closest hit are dropped
         has = false;
         while (sp > 0) {
             sp--;
-            const uint32_t w = __float_as_uint(stk_lb[sp * bs]);
-            if (prune(__uint_as_float(w & 0x7FFFFFFFu), best_slot >= 0, best)) continue;
-            amb = (w >> 31) != 0;
-            enter((int)stk_node[sp * bs]);
+            const uint2 e = (uint32_t)sp < lds_levels ? stk[sp * bs] : stk_deep[(sp - lds_levels) * deep_stride];
+            if (__uint_as_float(e.y) > thr) continue;
+            enter((int)e.x);
             break;
         }
+    };
+    auto accept = [&](float t, int s) {  // a legal candidate that beats the closest hit so far
+        best = t;
+        best_slot = s;
+        thr = t * 1.0001f + 1e-5f;
     };
 
     for (;;) {
@@ -251,26 +165,16 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 d = mk3(D[idx], D[plane_stride + idx], D[2 * plane_stride + idx]);
                 a = 0;
                 if (MODE != MIRT_MODE_UNCONDITIONAL) a = aux[idx];
-                contact = unpack_contact(a);
-                inside = unpack_inside(a);
                 best = -1.f;
+                thr = INF;
                 best_slot = -1;
                 sp = 0;
                 has = false;
-                amb = false;
                 active = true;
                 pre = ray_prepare(sc, o, d);
-                if (pre.fast) {
-                    float lb;
-                    bool un;
-                    if (classify(sc.root_lo, sc.root_hi, lb, un)) {
-                        amb = un;
-                        enter(__float_as_int(sc.root_lo.w));
-                    }
-                } else {
-                    defer[atomicAdd(queue + 1, 1u)] = idx;  // outside the classifier's error model
-                    active = false;
-                }
+                float lb;
+                const int code = slab_classify(sc.root_lo, sc.root_hi, box_is_flat(sc.root_lo, sc.root_hi), o, pre, lb);
+                if (resolve(sc.root_lo, sc.root_hi, code, lb)) enter(__float_as_int(sc.root_lo.w));
             }
             pool_next += take;
         }
@@ -291,34 +195,34 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             }
             const PairRec P = sc.pairs[link];
             float lbl, lbr;
-            bool ul, ur;
-            bool hl = classify(P.llo, P.lhi, lbl, ul);
-            bool hr = classify(P.rlo, P.rhi, lbr, ur);
-            const bool have = best_slot >= 0;
-            hl = hl && !prune(lbl, have, best);
-            hr = hr && !prune(lbr, have, best);
-            ul |= amb;
-            ur |= amb;
-            const int kl = __float_as_int(P.llo.w), kr = __float_as_int(P.rlo.w);
-            if (hl && hr) {
-                const bool lf = lbl <= lbr;
-                stk_node[sp * bs] = (uint32_t)(lf ? kr : kl);
-                stk_lb[sp * bs] = __uint_as_float(__float_as_uint(lf ? lbr : lbl) | ((lf ? ur : ul) ? 0x80000000u : 0u));
-                sp++;
-                amb = lf ? ul : ur;
-                enter(lf ? kl : kr);
-            } else if (hl) {
-                amb = ul;
-                enter(kl);
-            } else if (hr) {
-                amb = ur;
-                enter(kr);
-            } else {
-                pop();
+            const int cl = slab_classify(P.llo, P.lhi, __float_as_int(P.lhi.w) != 0, o, pre, lbl);
+            const int cr = slab_classify(P.rlo, P.rhi, __float_as_int(P.rhi.w) != 0, o, pre, lbr);
+            bool vl = cl == BOX_HIT, vr = cr == BOX_HIT;
+            if (COUNT || !pre.fast || cl == BOX_AMBIGUOUS || cr == BOX_AMBIGUOUS) {
+                vl = resolve(P.llo, P.lhi, cl, lbl);
+                vr = resolve(P.rlo, P.rhi, cr, lbr);
             }
+            vl &= !(lbl > thr);
+            vr &= !(lbr > thr);
+            const int kl = __float_as_int(P.llo.w), kr = __float_as_int(P.rlo.w);
+            const bool pick_l = vl & (!vr | (lbl <= lbr));  // nearer child first
+            if (vl & vr) {
+                const uint2 e = make_uint2((uint32_t)(pick_l ? kr : kl), __float_as_uint(pick_l ? lbr : lbl));
+                if ((uint32_t)sp < lds_levels)
+                    stk[sp * bs] = e;
+                else
+                    stk_deep[(sp - lds_levels) * deep_stride] = e;
+                sp++;
+            }
+            if (vl | vr)
+                enter(pick_l ? kl : kr);
+            else
+                pop();
         }
 
-        // ---- leaf phase: up to LEAF_BATCH triangles of this lane's leaf ------------------------------
+        // ---- leaf phase: up to LEAF_BATCH triangles of this lane's leaf. In NO_SELF mode a lane
+        // stops at its first candidate; the predicate (shading normal) is evaluated once per pass for
+        // all such lanes together instead of inside the triangle loop. --------------------------------
         if (COUNT) {
             int trips = (active && has) ? min(LEAF_BATCH, leaf_end - leaf_pos) : 0;
             for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off));
@@ -327,29 +231,45 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 au.w_outer++;
             }
         }
-        if (active && has) {
-            const int stop = min(leaf_pos + LEAF_BATCH, leaf_end);
-            for (int s = leaf_pos; s < stop; s++) {
-                const TriRec T = sc.tris[s];
-                if (COUNT) au.tri++;
-                const float t = tri_test(T, o, d);
-                if (!(t >= 0.f)) continue;
-                if (!(best_slot < 0 || t < best || (t == best && best_slot < leaf_beg))) continue;
-                if (!candidate_legal<MODE>(sc, T, s, o, d, t, a, contact, inside)) continue;
-                if (amb) {
-                    // the closest hit would rest on a box the classifier could not prove: retrace
-                    // this ray with the exact test (k_intersect_exact)
-                    if (COUNT) au.walk++;
-                    defer[atomicAdd(queue + 1, 1u)] = idx;
-                    active = false;
-                    break;
+        {
+            const int stop = (active && has) ? min(leaf_pos + LEAF_BATCH, leaf_end) : 0;
+            const int leaf_beg = (int)(~(uint32_t)link & 0xFFFFFFu);
+            bool more = active && has;
+            for (;;) {
+                int cand = -1;
+                float cand_t = 0.f;
+                if (more) {
+                    int s = leaf_pos;
+                    for (; s < stop; s++) {
+                        const TriRec T = sc.tris[s];
+                        if (COUNT) au.tri++;
+                        const float t = tri_test(T, o, d);
+                        if (!(t >= 0.f)) continue;
+                        if (!(best_slot < 0 || t < best || (t == best && best_slot < leaf_beg))) continue;
+                        if (MODE == MIRT_MODE_NO_SELF) {
+                            cand = s;
+                            cand_t = t;
+                            s++;
+                            break;
+                        }
+                        if (MODE == MIRT_MODE_LAST_TID && __float_as_int(sc.vns[s].n1.w) == a) continue;
+                        accept(t, s);
+                    }
+                    leaf_pos = s;
                 }
-                best = t;
-                best_slot = s;
+                if (MODE != MIRT_MODE_NO_SELF) break;
+                if (cand >= 0) {
+                    const VnRec V = sc.vns[cand];
+                    const f3 pos = o + d * cand_t;
+                    const f3 nn = world_normal(sc.tris[cand], V, __float_as_int(V.n2.w) != 0, pos);
+                    if (legal_noself(dot3(d, nn), __float_as_int(V.n0.w), unpack_contact(a), unpack_inside(a)))
+                        accept(cand_t, cand);
+                }
+                more = active && has && leaf_pos < stop;
+                if (!__any(more)) break;
             }
-            leaf_pos = stop;
-            if (active && leaf_pos >= leaf_end) pop();
         }
+        if (active && has && leaf_pos >= leaf_end) pop();
 
         // ---- retire finished rays -----------------------------------------------------------------
         if (active && !has) {

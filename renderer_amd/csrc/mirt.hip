@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,17 +25,17 @@ struct MirtContext {
     std::string err;
     std::string info;
     // scene
-    NodeRec* d_nodes = nullptr;
     PairRec* d_pairs = nullptr;
     TriRec* d_tris = nullptr;
     VnRec* d_vns = nullptr;
     DevObject* d_objs = nullptr;
-    int* d_parents = nullptr;
     DevScene sc{};
     bool has_scene = false;
     bool has_unsupported = false;  // scene holds an object kind the shade kernel cannot scatter yet
     int block = 256;
-    size_t lds = 0;
+    size_t lds_main = 0;   // the first lds_levels stack levels live in LDS, deeper ones in d_spill
+    uint32_t lds_levels = 0;
+    uint2* d_spill = nullptr;
     // wavefront path state
     PathBuf pb[2]{};
     size_t pb_cap = 0;
@@ -42,9 +43,7 @@ struct MirtContext {
     uint32_t* d_cnt = nullptr;   // [2] live-path counters (ping-pong)
     uint32_t* h_cnt = nullptr;   // pinned
     unsigned long long* d_counters = nullptr;  // [8] audit counters of the instrumented kernel
-    uint32_t* d_queue = nullptr;               // [0] ray queue head, [1] deferred-ray count
-    uint32_t* d_defer = nullptr;               // indices of rays handed to the exact kernel
-    size_t defer_cap = 0;
+    uint32_t* d_queue = nullptr;               // ray queue head of the running launch
     int n_cus = 256;
     int max_blocks = 1024;                     // resident blocks of the intersect kernel (grid cap)
     // staging for the host-pointer intersect
@@ -149,15 +148,13 @@ int mirt_create(int device, MirtContext** out) {
 }
 
 static void free_scene(MirtContext* ctx) {
-    hipFree(ctx->d_nodes);
     hipFree(ctx->d_pairs);
     ctx->d_pairs = nullptr;
     hipFree(ctx->d_tris);
     hipFree(ctx->d_vns);
     hipFree(ctx->d_objs);
-    hipFree(ctx->d_parents);
-    ctx->d_parents = nullptr;
-    ctx->d_nodes = nullptr;
+    hipFree(ctx->d_spill);
+    ctx->d_spill = nullptr;
     ctx->d_tris = nullptr;
     ctx->d_vns = nullptr;
     ctx->d_objs = nullptr;
@@ -195,7 +192,6 @@ int mirt_destroy(MirtContext* ctx) {
     hipFree(ctx->d_cnt);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_queue);
-    hipFree(ctx->d_defer);
     if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -283,24 +279,7 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
             return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: tri_obj out of range");
     }
 
-    std::vector<NodeRec> nodes(N);
-    for (int i = 0; i < N; i++) {
-        int r = s->node_right[i];
-        int c0 = r >= 0 ? r : ~s->node_leaf_begin[i];
-        int c1 = r >= 0 ? 0 : s->node_leaf_end[i];
-        float f0, f1;
-        memcpy(&f0, &c0, 4);
-        memcpy(&f1, &c1, 4);
-        nodes[i].lo = make_float4(s->node_min[3 * i], s->node_min[3 * i + 1], s->node_min[3 * i + 2], f0);
-        nodes[i].hi = make_float4(s->node_max[3 * i], s->node_max[3 * i + 1], s->node_max[3 * i + 2], f1);
-    }
-    // parent links (ancestor-chain verification) and the facts the slab classifier's error model needs
-    std::vector<int> parents(N, -1);
-    for (int i = 0; i < N; i++)
-        if (s->node_right[i] >= 0) {
-            parents[i + 1] = i;
-            parents[s->node_right[i]] = i;
-        }
+    // the facts the slab classifier's error model needs
     float bound[3] = {0.f, 0.f, 0.f};
     int fast_ok = 1;
     for (int i = 0; i < N; i++)
@@ -312,11 +291,9 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
             }
     // breadth-first child pairs
     if (T > (1 << 24)) return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: more than 2^24 triangles");
-    std::vector<int> slot_leaf(T, 0);
     auto link_of_leaf = [&](int i, int* out) -> bool {
         int b = s->node_leaf_begin[i], cnt = s->node_leaf_end[i] - b;
         if (cnt > 127) return false;
-        for (int k = b; k < b + cnt; k++) slot_leaf[k] = i;
         *out = ~(int)((uint32_t)b | ((uint32_t)cnt << 24));
         return true;
     };
@@ -339,9 +316,12 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         int lk;
         if (s->node_right[c] >= 0) lk = pair_of[c];
         else if (!link_of_leaf(c, &lk)) return false;
+        const float* mn = s->node_min + 3 * c;
+        const float* mx = s->node_max + 3 * c;
+        int flat = (mn[0] == mx[0]) | (mn[1] == mx[1]) | (mn[2] == mx[2]);
         float fl, fn;
         memcpy(&fl, &lk, 4);
-        memcpy(&fn, &c, 4);
+        memcpy(&fn, &flat, 4);
         *lo = make_float4(s->node_min[3 * c], s->node_min[3 * c + 1], s->node_min[3 * c + 2], fl);
         *hi = make_float4(s->node_max[3 * c], s->node_max[3 * c + 1], s->node_max[3 * c + 2], fn);
         return true;
@@ -370,12 +350,15 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         int ob = s->tri_obj[g];
         memcpy(&fo, &ob, 4);
         memcpy(&fg, &g, 4);
-        const float* vn = s->tri_vn ? s->tri_vn + 9 * (size_t)g : nullptr;
-        vns[k].n0 = make_float4(vn ? vn[0] : 0.f, vn ? vn[1] : 0.f, vn ? vn[2] : 0.f, fo);
+        const int hv = s->objects[ob].has_vn != 0;
+        const float* vn = hv ? s->tri_vn + 9 * (size_t)g : nullptr;
+        // without vertex normals the shading normal is the face normal (SimpleShape.cpp:300-339)
+        h3 fnrm = hnormalize(hcross(hsub(v1, v0), hsub(v2, v0)));
+        vns[k].n0 = make_float4(vn ? vn[0] : fnrm.x, vn ? vn[1] : fnrm.y, vn ? vn[2] : fnrm.z, fo);
         vns[k].n1 = make_float4(vn ? vn[3] : 0.f, vn ? vn[4] : 0.f, vn ? vn[5] : 0.f, fg);
-        float fl;
-        memcpy(&fl, &slot_leaf[k], 4);
-        vns[k].n2 = make_float4(vn ? vn[6] : 0.f, vn ? vn[7] : 0.f, vn ? vn[8] : 0.f, fl);
+        float fh;
+        memcpy(&fh, &hv, 4);
+        vns[k].n2 = make_float4(vn ? vn[6] : 0.f, vn ? vn[7] : 0.f, vn ? vn[8] : 0.f, fh);
     }
     std::vector<DevObject> objs(s->n_objects);
     for (int o = 0; o < s->n_objects; o++) {
@@ -396,22 +379,16 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
-    HIPCHK(ctx, hipMalloc(&ctx->d_nodes, sizeof(NodeRec) * (size_t)N));
     HIPCHK(ctx, hipMalloc(&ctx->d_pairs, sizeof(PairRec) * pairs.size()));
     HIPCHK(ctx, hipMemcpy(ctx->d_pairs, pairs.data(), sizeof(PairRec) * pairs.size(), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMalloc(&ctx->d_tris, sizeof(TriRec) * (size_t)T));
     HIPCHK(ctx, hipMalloc(&ctx->d_vns, sizeof(VnRec) * (size_t)T));
     HIPCHK(ctx, hipMalloc(&ctx->d_objs, sizeof(DevObject) * (size_t)s->n_objects));
-    HIPCHK(ctx, hipMemcpy(ctx->d_nodes, nodes.data(), sizeof(NodeRec) * (size_t)N, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->d_tris, tris.data(), sizeof(TriRec) * (size_t)T, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->d_vns, vns.data(), sizeof(VnRec) * (size_t)T, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->d_objs, objs.data(), sizeof(DevObject) * (size_t)s->n_objects, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMalloc(&ctx->d_parents, sizeof(int) * (size_t)N));
-    HIPCHK(ctx, hipMemcpy(ctx->d_parents, parents.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice));
-    ctx->sc.parents = ctx->d_parents;
     for (int c = 0; c < 3; c++) ctx->sc.bound[c] = bound[c];
     ctx->sc.fast_ok = fast_ok;
-    ctx->sc.nodes = ctx->d_nodes;
     ctx->sc.pairs = ctx->d_pairs;
     ctx->sc.root_lo = root_lo;
     ctx->sc.root_hi = root_hi;
@@ -422,16 +399,33 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     ctx->sc.n_tris = T;
     ctx->sc.n_objects = s->n_objects;
     ctx->sc.depth = depth;
-    // per-lane stack: (depth+1) levels x (node index, entry distance) x block lanes, in LDS
-    ctx->block = (size_t)(depth + 1) * 8 * 256 <= 65536 ? 256 : 64;
-    ctx->lds = (size_t)(depth + 1) * 8 * ctx->block;
+    // per-lane stack: (depth+1) levels x (child link, entry distance) x block lanes. Only as many
+    // levels live in LDS as still let the register-limited number of blocks stay resident; deeper
+    // pushes (rare: the stack holds the far siblings of the current path, a handful) go to a global
+    // spill area.
+    ctx->block = 256;
+    hipFuncAttributes fa{};
+    int by_regs = 4;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_intersect<MIRT_MODE_NO_SELF, false, false>)) == hipSuccess &&
+        fa.numRegs > 0)
+        by_regs = std::max(1, std::min(8, 512 / ((fa.numRegs + 7) / 8 * 8)));  // waves per SIMD
+    const int waves_per_block = std::max(1, ctx->block / 64);
+    const int want_blocks = std::max(1, by_regs * 4 / waves_per_block);
+    size_t lds_budget = (size_t)160 * 1024 / want_blocks;
+    uint32_t levels = (uint32_t)std::min<size_t>((size_t)depth + 1, std::max<size_t>(4, lds_budget / (8 * (size_t)ctx->block)));
+    if (const char* e = getenv("MIRT_LDS_LEVELS")) levels = (uint32_t)std::min<long>(depth + 1, std::max<long>(1, atol(e)));
+    ctx->lds_levels = levels;
+    ctx->lds_main = (size_t)levels * 8 * ctx->block;
     // persistent grid: as many blocks as stay resident (a larger grid would only queue; smaller
     // batches launch fewer). The occupancy answer is advisory, nothing waits on co-residency.
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_intersect<MIRT_MODE_NO_SELF, false, false>,
-                                                     ctx->block, ctx->lds) != hipSuccess || occ < 1)
+                                                     ctx->block, ctx->lds_main) != hipSuccess || occ < 1)
         occ = 1;
     ctx->max_blocks = occ * ctx->n_cus;
+    const size_t spill_levels = (size_t)depth + 1 - levels;
+    if (spill_levels)
+        HIPCHK(ctx, hipMalloc(&ctx->d_spill, spill_levels * (size_t)ctx->max_blocks * ctx->block * sizeof(uint2)));
     ctx->has_scene = true;
     ctx->has_unsupported = unsupported;
     return MIRT_OK;
@@ -443,30 +437,18 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
 template <int MODE, bool COUNT, bool SLOT_OUT>
 static void launch_pair(MirtContext* ctx, hipStream_t st, dim3 grid, dim3 block, const float* O, const float* D,
                         const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out) {
-    hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT>), grid, block, ctx->lds, st, ctx->sc, O, D, aux, n,
-                       stride, t_out, id_out, ctx->d_counters, ctx->d_queue, ctx->d_defer);
-    // the deferred rays (usually a handful): exact reference box test throughout
-    hipLaunchKernelGGL((k_intersect_exact<MODE, COUNT, SLOT_OUT>), dim3(std::min<uint32_t>(grid.x, 64)), block,
-                       ctx->lds, st, ctx->sc, O, D, aux, stride, t_out, id_out, ctx->d_counters, ctx->d_defer,
-                       ctx->d_queue + 1);
+    hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT>), grid, block, ctx->lds_main, st, ctx->sc, O, D, aux, n,
+                       stride, t_out, id_out, ctx->d_counters, ctx->d_queue, ctx->lds_levels, ctx->d_spill);
 }
 
 template <bool COUNT, bool SLOT_OUT>
 static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
                             const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out) {
     if (n == 0) return MIRT_OK;
-    if (n > ctx->defer_cap) {  // grows only when a larger batch than ever before arrives
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        hipFree(ctx->d_defer);
-        ctx->d_defer = nullptr;
-        ctx->defer_cap = 0;
-        HIPCHK(ctx, hipMalloc(&ctx->d_defer, sizeof(uint32_t) * (size_t)n));
-        ctx->defer_cap = n;
-    }
     const uint32_t want = (n + ctx->block - 1) / ctx->block;
     dim3 block(ctx->block), grid(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks));
-    // queue head and deferred-ray count start at zero for every launch
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(uint32_t), st));
+    // the queue head starts at zero for every launch
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), st));
     switch (mode) {
         case MIRT_MODE_UNCONDITIONAL:
             launch_pair<MIRT_MODE_UNCONDITIONAL, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, stride, t_out, id_out);

@@ -19,11 +19,12 @@ namespace mirt {
 // node record, 32 B, pre-order (left child = i+1):
 //   lo = (min.x, min.y, min.z, bits(c0))   hi = (max.x, max.y, max.z, bits(c1))
 //   inner: c0 = right child index (> 0), c1 = 0        leaf: c0 = ~leaf_begin (< 0), c1 = leaf_end
-struct NodeRec {
+struct NodeRec {  // (unused by the kernels since the pair layout; kept for tools)
     float4 lo, hi;
 };
 // traversal record, 64 B: the two children of one inner node, in BREADTH-FIRST order of the inner
-// nodes (the top of the tree is contiguous). Per child: (min.xyz, bits link), (max.xyz, bits node id)
+// nodes (the top of the tree is contiguous). Per child: (min.xyz, bits link), (max.xyz, bits flat)
+//   flat != 0: the box has zero extent along at least one axis (slab_classify)
 //   link >= 0: index of the child's own PairRec (inner node)
 //   link <  0: leaf, ~link = first slot | (triangle count << 24)
 struct PairRec {
@@ -36,9 +37,11 @@ struct TriRec {
     float4 a, b, c;
 };
 // per-slot shading data, 48 B, touched only for candidate hits that would win (predicate) and in
-// the shade kernel: corner normals (normal-matrix transformed, not normalised).
+// the shade kernel: corner normals (normal-matrix transformed, not normalised); for a triangle of an
+// object without vertex normals n0.xyz is its face normal normalize((v1-v0) x (v2-v0))
+// (SimpleShape.cpp:300-339), rounded on the host exactly as the reference rounds it per query.
 struct VnRec {
-    float4 n0, n1, n2;  // .w: n0 bits(object id), n1 bits(global tid), n2 bits(pre-order id of the leaf)
+    float4 n0, n1, n2;  // .w: n0 bits(object id), n1 bits(global tid), n2 bits(object has vertex normals)
 };
 
 struct DevObject {
@@ -50,13 +53,11 @@ struct DevObject {
 };
 
 struct DevScene {
-    const NodeRec* nodes;  // pre-order records: exact-path traversal and ancestor verification
     const PairRec* pairs;  // breadth-first child pairs: the classifier-path traversal
     float4 root_lo, root_hi;  // root box; root_lo.w = bits(link of the root)
     const TriRec* tris;
     const VnRec* vns;
     const DevObject* objects;
-    const int* parents;   // parent node index, -1 for the root (ancestor-chain verification)
     int n_nodes, n_tris, n_objects, depth;
     float bound[3];       // max |coordinate| of the root box per axis
     int fast_ok;          // every node bound is 0 or in [2^-36, 2^60): the slab classifier may be used
@@ -183,8 +184,8 @@ __device__ __forceinline__ RayPre ray_prepare(const DevScene& sc, f3 o, f3 d) {
     return p;
 }
 
-__device__ __forceinline__ int slab_classify(const float4 lo, const float4 hi, f3 o, const RayPre& p,
-                                             float& lb) {
+__device__ __forceinline__ int slab_classify(const float4 lo, const float4 hi, bool flat, f3 o,
+                                             const RayPre& p, float& lb) {
     const float t0x = (lo.x - o.x) * p.inv.x, t1x = (hi.x - o.x) * p.inv.x;
     const float t0y = (lo.y - o.y) * p.inv.y, t1y = (hi.y - o.y) * p.inv.y;
     const float t0z = (lo.z - o.z) * p.inv.z, t1z = (hi.z - o.z) * p.inv.z;
@@ -193,21 +194,22 @@ __device__ __forceinline__ int slab_classify(const float4 lo, const float4 hi, f
     const float nz = fminf(t0z, t1z), fz = fmaxf(t0z, t1z);
     const float tn = fmaxf(nx, fmaxf(ny, nz)), n2 = __builtin_amdgcn_fmed3f(nx, ny, nz);
     const float tf = fminf(fx, fminf(fy, fz)), f2 = __builtin_amdgcn_fmed3f(fx, fy, fz);
-    const float M = p.a_ray + 1.9073486e-06f /*32 * 2^-24*/ * (fabsf(tn) + fabsf(tf));
-    const float gap = tf - tn;
-    const bool sep_top = tn - n2 > M, sep_bot = f2 - tf > M;
+    // one fused multiply-add: never below the two-rounding value the derivation assumes
+    const float M = __builtin_fmaf(1.9073486e-06f /*32 * 2^-24*/, fabsf(tn) + fabsf(tf), p.a_ray);
+    const float gap = tf - tn, e_top = tn - n2, e_bot = f2 - tf;
     lb = fmaxf(tn, 0.f);
-    bool ok_gap = gap > M, behind_flat = false;
-    if (!ok_gap && gap >= 0.f) {
-        // entry and exit value of the SAME axis (a thin or flat box, e.g. an axis-aligned wall): the
-        // two never cross, so only the separation from the other axes matters
-        const bool same = ((nx == tn) & (fx == tf)) | ((ny == tn) & (fy == tf)) | ((nz == tn) & (fz == tf));
-        ok_gap = same;
-        behind_flat = same & (tn == tf) & (tf < 0.f);  // a flat box behind the origin (sign is exact)
-    }
-    if (ok_gap && ((tf >= 0.f && sep_bot) || (tn >= 0.f && sep_top))) return BOX_HIT;
-    if (tf < -M || (-gap > M && sep_top && sep_bot) || behind_flat) return BOX_MISS;
-    return BOX_AMBIGUOUS;
+    // a box of zero extent along an axis (an axis-aligned wall): that axis yields the same entry and
+    // exit value, bit for bit, so tn == tf means the other two slabs contain it and the two never cross
+    const bool on_flat = flat & (tn == tf);
+    const bool ok_gap = (gap > M) | on_flat;
+    // the face that decides the hit: the exit face, or (origin outside) the entry face as well
+    const float e = tn >= 0.f ? fmaxf(e_top, e_bot) : e_bot;
+    const bool hit = ok_gap & (tf >= 0.f) & (e > M);
+    const bool miss = (tf < -M) | (fminf(fminf(-gap, e_top), e_bot) > M) | (on_flat & (tf < 0.f));
+    return hit ? BOX_HIT : (miss ? BOX_MISS : BOX_AMBIGUOUS);
+}
+__device__ __forceinline__ bool box_is_flat(const float4 lo, const float4 hi) {
+    return (lo.x == hi.x) | (lo.y == hi.y) | (lo.z == hi.z);
 }
 
 // a subtree whose box starts beyond the closest accepted hit cannot change the result; the slack
@@ -236,9 +238,9 @@ __device__ __forceinline__ float tri_test(const TriRec& T, f3 o, f3 d) {
 
 // ---- shading normal (SimpleShape.cpp:300-339 through SceneObject.cpp:250-254) ------------------
 __device__ __forceinline__ f3 world_normal(const TriRec& T, const VnRec& V, bool has_vn, f3 pos) {
+    if (!has_vn) return mk3(V.n0.x, V.n0.y, V.n0.z);  // normalize((v1-v0) x (v2-v0)), rounded on the host at upload
     f3 v0 = mk3(T.a.x, T.a.y, T.a.z), v1 = mk3(T.b.x, T.b.y, T.b.z), v2 = mk3(T.c.x, T.c.y, T.c.z);
     f3 b1 = v1 - v0, b2 = v2 - v0;
-    if (!has_vn) return normalize3(cross3(b1, b2));
     f3 v = pos - v0;
     float d12 = dot3(b1, b2);
     float l1 = len3(b1), l2 = len3(b2);

@@ -66,6 +66,20 @@ def test_mesh20k(gpu, mesh20k, mesh20k_oracle, ra):
         _check(tg, ig, tc, ic, "mesh20k mode %d" % mode)
 
 
+def test_stack_spill_levels(gpu, mesh20k, mesh20k_oracle, ra, monkeypatch):
+    """Only the first levels of the per-lane stack live in LDS; with the cap forced down to 2 nearly
+    every push goes through the global spill area and the answers must not change."""
+    monkeypatch.setenv("MIRT_LDS_LEVELS", "2")
+    gpu.upload(mesh20k.describe())
+    monkeypatch.delenv("MIRT_LDS_LEVELS")
+    o, d, aux = meshgen.random_rays(200000, 41, mesh20k.n_objects, inside_obj=8)
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_NO_SELF, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = mesh20k_oracle.intersect(o, d, a, mode, threads=16)
+        m, ex = _check(tg, ig, tc, ic, "spill mode %d" % mode)
+        assert m == 1.0 and ex == 1.0
+
+
 def test_flat_shaded_mesh(gpu, ra, orc):
     """objects without vertex normals use the face normal (SimpleShape.cpp:313-316,324-327)"""
     s = meshgen.mesh_scene(3, smooth=False)
@@ -176,7 +190,8 @@ def test_classifier_audit(gpu, cornell, mesh20k, cornell_oracle, ra):
                                         ti.data_ptr())
             assert a["mismatch"] == 0, a
             assert a["ambiguous"] / a["box"] < 0.10, a  # even on this adversarial mix most boxes are proven
-            assert a["walks"] / n < 0.25, a
+            # exact tests run = unproven boxes + every box of the axis-parallel rays (outside the model)
+            assert a["ambiguous"] <= a["walks"] < 0.25 * a["box"], a
 
 
 def test_device_pointer_entry_and_streams(cornell_dev, cornell, cornell_oracle, ra):
