@@ -35,7 +35,7 @@
 namespace mirt {
 
 #ifndef MIRT_RAY_CHUNK
-#define MIRT_RAY_CHUNK 256
+#define MIRT_RAY_CHUNK 64
 #endif
 #ifndef MIRT_LEAF_BATCH
 #define MIRT_LEAF_BATCH 8
@@ -69,10 +69,13 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
 template <int MODE, bool COUNT, bool SLOT_OUT>
 __global__ void __launch_bounds__(256)
 k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ D,
-            const int* __restrict__ aux, uint32_t n, uint32_t plane_stride, float* __restrict__ t_out,
+            const int* __restrict__ aux, uint32_t n_direct, const uint32_t* __restrict__ n_ptr,
+            uint32_t plane_stride, float* __restrict__ t_out,
             int* __restrict__ id_out, unsigned long long* __restrict__ counters,
             uint32_t* __restrict__ queue, uint32_t lds_levels, uint2* __restrict__ spill) {
     extern __shared__ uint32_t lds[];
+    // ray count: given, or (wavefront path tracer) left in device memory by the previous shade pass
+    const uint32_t n = n_ptr ? min(*n_ptr, n_direct) : n_direct;
     const uint32_t bs = blockDim.x;
     // per-lane stack, [level][lane] of (child link, entry distance): the first
     // lds_levels levels in LDS, deeper ones (rarely reached) in the global spill area

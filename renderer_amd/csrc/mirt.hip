@@ -40,8 +40,10 @@ struct MirtContext {
     PathBuf pb[2]{};
     size_t pb_cap = 0;
     float* d_L = nullptr;
-    uint32_t* d_cnt = nullptr;   // [2] live-path counters (ping-pong)
-    uint32_t* h_cnt = nullptr;   // pinned
+    uint32_t* d_cnt = nullptr;   // [cnt_cap] live paths after k bounces of the running wavefront
+    uint32_t* d_wq = nullptr;    // [cnt_cap] ray-queue heads, one per intersect launch of the wavefront
+    uint32_t* h_cnt = nullptr;   // pinned, [cnt_cap]
+    size_t cnt_cap = 0;
     unsigned long long* d_counters = nullptr;  // [8] audit counters of the instrumented kernel
     uint32_t* d_queue = nullptr;               // ray queue head of the running launch
     int n_cus = 256;
@@ -135,9 +137,7 @@ int mirt_create(int device, MirtContext** out) {
         ctx->info = buf;
         ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    if ((e = hipMalloc(&ctx->d_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipHostMalloc(&ctx->h_cnt, 4 * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess ||
+    if ((e = hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc(&ctx->d_queue, 64 * sizeof(uint32_t))) != hipSuccess) {
         g_create_err = std::string("mirt_create: ") + hipGetErrorString(e);
         delete ctx;
@@ -190,6 +190,7 @@ int mirt_destroy(MirtContext* ctx) {
     free_staging(ctx);
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     hipFree(ctx->d_cnt);
+    hipFree(ctx->d_wq);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_queue);
     if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
@@ -436,28 +437,35 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
 // ---- launches -------------------------------------------------------------------------------------
 template <int MODE, bool COUNT, bool SLOT_OUT>
 static void launch_pair(MirtContext* ctx, hipStream_t st, dim3 grid, dim3 block, const float* O, const float* D,
-                        const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out) {
+                        const int* aux, uint32_t n, const uint32_t* n_ptr, uint32_t stride, float* t_out,
+                        int* id_out, uint32_t* queue) {
     hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT>), grid, block, ctx->lds_main, st, ctx->sc, O, D, aux, n,
-                       stride, t_out, id_out, ctx->d_counters, ctx->d_queue, ctx->lds_levels, ctx->d_spill);
+                       n_ptr, stride, t_out, id_out, ctx->d_counters, queue, ctx->lds_levels, ctx->d_spill);
 }
 
+// n_ptr == nullptr: n rays, grid sized to n. n_ptr != nullptr: the count is read on the device
+// (at most n), grid sized to the chip; `queue` is the launch's own zeroed queue word.
 template <bool COUNT, bool SLOT_OUT>
 static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
-                            const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out) {
+                            const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out,
+                            const uint32_t* n_ptr = nullptr, uint32_t* queue = nullptr) {
     if (n == 0) return MIRT_OK;
     const uint32_t want = (n + ctx->block - 1) / ctx->block;
     dim3 block(ctx->block), grid(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks));
-    // the queue head starts at zero for every launch
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), st));
+    if (!queue) {
+        // the queue head starts at zero for every launch
+        queue = ctx->d_queue;
+        HIPCHK(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), st));
+    }
     switch (mode) {
         case MIRT_MODE_UNCONDITIONAL:
-            launch_pair<MIRT_MODE_UNCONDITIONAL, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, stride, t_out, id_out);
+            launch_pair<MIRT_MODE_UNCONDITIONAL, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue);
             break;
         case MIRT_MODE_LAST_TID:
-            launch_pair<MIRT_MODE_LAST_TID, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, stride, t_out, id_out);
+            launch_pair<MIRT_MODE_LAST_TID, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue);
             break;
         case MIRT_MODE_NO_SELF:
-            launch_pair<MIRT_MODE_NO_SELF, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, stride, t_out, id_out);
+            launch_pair<MIRT_MODE_NO_SELF, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue);
             break;
         default:
             return fail(ctx, MIRT_E_INVALID, "intersect: unknown mode");
@@ -623,6 +631,9 @@ static hipEvent_t get_event(MirtContext* ctx, size_t k) {
 }
 
 // One wavefront of `S` samples per pixel starting at global sample index s0.
+// The live-path count of every bounce stays on the device (d_cnt[depth]); the host enqueues the
+// whole bounce sequence and looks at a count only now and then (to stop early) or when rays are
+// being captured. *n_rays_dev accumulates the rays traced.
 static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRenderParams* prm,
                          uint32_t s0, uint32_t S, float* rgb_sum, Capture* cap, uint64_t* n_rays,
                          size_t* ev_used) {
@@ -632,40 +643,62 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
     const int B = 256;
     PathBuf* cur = &ctx->pb[0];
     PathBuf* nxt = &ctx->pb[1];
+    const size_t words = (size_t)prm->max_depth + 4;
+    if (words > ctx->cnt_cap) {
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        hipFree(ctx->d_cnt);
+        hipFree(ctx->d_wq);
+        hipHostFree(ctx->h_cnt);
+        ctx->d_cnt = ctx->d_wq = ctx->h_cnt = nullptr;
+        ctx->cnt_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_cnt, words * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc(&ctx->d_wq, words * sizeof(uint32_t)));
+        HIPCHK(ctx, hipHostMalloc(&ctx->h_cnt, words * sizeof(uint32_t)));
+        ctx->cnt_cap = words;
+    }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_L, 0, 3 * ctx->pb_cap * sizeof(float), st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt, 0, words * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_wq, 0, words * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_generate, dim3((P + B - 1) / B), dim3(B), 0, st, cam, P, s0, prm->seed, cur->o,
                        cur->d, cur->stride, *cur, 1);
     HIPCHK(ctx, hipGetLastError());
-    auto timed_intersect = [&](int mode, PathBuf* pb, uint32_t n) -> int {
+    auto timed_intersect = [&](int mode, PathBuf* pb, uint32_t n, const uint32_t* n_ptr, uint32_t* queue) -> int {
         hipEvent_t e0 = get_event(ctx, *ev_used), e1 = get_event(ctx, *ev_used + 1);
         if (!e0 || !e1) return fail(ctx, MIRT_E_HIP, "hipEventCreate failed");
         *ev_used += 2;
         HIPCHK(ctx, hipEventRecord(e0, st));
         int rc = launch_intersect<false, true>(ctx, st, mode, pb->o, pb->d, pb->ids, n, pb->stride,
-                                               pb->t, pb->slot);
+                                               pb->t, pb->slot, n_ptr, queue);
         if (rc != MIRT_OK) return rc;
         HIPCHK(ctx, hipEventRecord(e1, st));
         return MIRT_OK;
     };
-    int rc = timed_intersect(MIRT_MODE_UNCONDITIONAL, cur, P);  // Camera.cpp:27-33: no predicate
+    // d_cnt[k] = paths alive after k bounces (k >= 1); the camera pass has P
+    int rc = timed_intersect(MIRT_MODE_UNCONDITIONAL, cur, P, nullptr, ctx->d_wq);  // Camera.cpp:27-33: no predicate
     if (rc != MIRT_OK) return rc;
-    *n_rays += P;
-    uint32_t n = P;
-    for (uint32_t depth = 0; depth <= prm->max_depth && n > 0; depth++) {
-        uint32_t* cnt = ctx->d_cnt + (depth & 1);
-        HIPCHK(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_shade, dim3((n + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, nullptr, n,
-                           *nxt, cnt, ctx->d_L, (uint32_t)ctx->pb_cap, depth, prm->max_depth);
+    uint32_t bound = P;  // host-side upper bound of the live paths
+    uint32_t depths_run = 0;
+    for (uint32_t depth = 0; depth <= prm->max_depth; depth++) {
+        const uint32_t* n_in = depth ? ctx->d_cnt + depth : nullptr;
+        uint32_t* n_out = ctx->d_cnt + depth + 1;
+        hipLaunchKernelGGL(k_shade, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in, bound,
+                           *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, depth, prm->max_depth);
         HIPCHK(ctx, hipGetLastError());
+        depths_run = depth + 1;
         if (depth == prm->max_depth) break;  // nothing survives the depth cap (MCRenderer.cpp:187-191)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        n = ctx->h_cnt[0];
-        if (n == 0) break;
-        if (n > P) return fail(ctx, MIRT_E_HIP, "wavefront: live-path counter corrupted");
         std::swap(cur, nxt);
+        // look at the count when capturing, and at depths 4, 8, 16, ... to stop early / shrink grids
+        const bool look = cap || (depth >= 3 && ((depth + 1) & depth) == 0);
+        if (look) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, n_out, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            const uint32_t n = ctx->h_cnt[0];
+            if (n > bound) return fail(ctx, MIRT_E_HIP, "wavefront: live-path counter corrupted");
+            bound = n;
+            if (n == 0) break;
+        }
         if (cap && depth + 1 >= cap->depth_lo && depth + 1 <= cap->depth_hi && cap->count < cap->capacity) {
-            size_t m = std::min((size_t)n, cap->capacity - cap->count);
+            size_t m = std::min((size_t)bound, cap->capacity - cap->count);
             for (int c = 0; c < 3; c++) {
                 HIPCHK(ctx, hipMemcpyAsync(cap->o + c * cap->capacity + cap->count, cur->o + (size_t)c * cur->stride,
                                            m * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -675,15 +708,19 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
             HIPCHK(ctx, hipMemcpyAsync(cap->aux + cap->count, cur->ids, m * sizeof(int), hipMemcpyDeviceToDevice, st));
             cap->count += m;
         }
-        rc = timed_intersect(MIRT_MODE_NO_SELF, cur, n);  // MCRenderer.cpp:193-197
+        rc = timed_intersect(MIRT_MODE_NO_SELF, cur, bound, n_out, ctx->d_wq + depth + 1);  // MCRenderer.cpp:193-197
         if (rc != MIRT_OK) return rc;
-        *n_rays += n;
     }
     if (rgb_sum) {
         hipLaunchKernelGGL(k_accumulate, dim3((wh + B - 1) / B), dim3(B), 0, st, ctx->d_L,
                            (uint32_t)ctx->pb_cap, wh, S, rgb_sum);
         HIPCHK(ctx, hipGetLastError());
     }
+    // rays traced by this wavefront = P + sum of the live counts (read after the stream drains)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, (depths_run + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    *n_rays += P;
+    for (uint32_t k = 1; k < depths_run + 1 && k <= prm->max_depth; k++) *n_rays += ctx->h_cnt[k];
     return MIRT_OK;
 }
 
@@ -702,7 +739,7 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint64_t wh = (uint64_t)cam.width * cam.height;
     uint32_t S = prm->spp_per_launch;
-    if (S == 0) S = (uint32_t)std::max<uint64_t>(1, (1ull << 22) / wh);  // ~4 Mi paths in flight
+    if (S == 0) S = (uint32_t)std::max<uint64_t>(1, (1ull << 24) / wh);  // ~16 Mi paths in flight (~2.2 GB of path state)
     S = std::min<uint32_t>(S, std::max<uint32_t>(prm->spp_count, 1));
     if (wh * S > (1ull << 30)) return fail(ctx, MIRT_E_LIMIT, "render: more than 2^30 paths per wavefront");
     rc = ensure_paths(ctx, (size_t)(wh * S));

@@ -162,6 +162,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
     __shared__ uint32_t s_wcnt[4];
     __shared__ uint32_t s_base;
     const uint32_t n = n_in ? min(*n_in, n_max) : n_max;
+    if (blockIdx.x * blockDim.x >= n) return;  // the grid is sized for n_max; whole block, before any barrier
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 
     bool alive = false;
