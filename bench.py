@@ -189,6 +189,16 @@ def main():
         # dominant kernel: k_intersect<NO_SELF> over the secondary batch
         sec_bytes = algorithmic_bytes(n_sec, sb, str_)
         ach = sec_bytes / (sec_ms * 1e-3) / 1e9 if sec_ms > 0 else 0.0
+        # HBM-side bytes of one launch of this kernel on this batch: PMC counters cannot be read from
+        # inside this process, so the figure comes from the committed rocprofv3 --pmc passes of this
+        # same command (profiles/, scripts/profile_gpu.sh); null when that profile is of another batch
+        traffic_bytes, traffic_src = None, None
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_current_traffic.json")
+        if os.path.exists(tj) and n_sec == 12582912:
+            k = json.load(open(tj))["kernels"].get("k_intersect<2, false, false>")
+            if k:
+                traffic_bytes = int(k["read_bytes"] + k["write_bytes"])
+                traffic_src = "profiles/r1_current_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean of %d dispatches)" % k["dispatches"]
         out["roofline"] = {
             "bound": "hbm",
             "kernel": "k_intersect<MODE_NO_SELF> (secondary batch, %d rays)" % n_sec,
@@ -196,7 +206,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic_bytes,
+            "traffic_source": traffic_src,
             "kernel_ms": round(sec_ms, 4),
             "algorithmic_bytes_per_launch": sec_bytes,
             "bytes_per_ray": round(sec_bytes / n_sec, 1),

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Summarises a scripts/profile_gpu.sh output directory into one text file (for profiles/).
-usage: summarize_profile.py gpurun_out/prof_r1 > profiles/r1_summary.txt"""
-import csv, glob, os, re, sys
+usage: summarize_profile.py gpurun_out/prof_r1 [traffic.json] > profiles/r1_summary.txt
+With a second argument the HBM-side bytes per dispatch of every kernel (FETCH_SIZE doubled as the
+guide prescribes for gfx950 and as the known ray-input byte count confirms, plus WRITE_SIZE) are
+also written as JSON; bench.py reports them as roofline.traffic."""
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 d = sys.argv[1]
@@ -9,7 +12,7 @@ def short(name):
     name = re.sub(r"\(.*", "", name).replace("void ", "").replace("mirt::", "")
     return name[:70]
 print("# rocprofv3 summary of: python3 bench.py --steps N --warmup 1 --no-cpu --pt-spp 8 (scripts/profile_gpu.sh)")
-for f in glob.glob(os.path.join(d, "kt", "*", "*_kernel_stats.csv")):
+for f in sorted(glob.glob(os.path.join(d, "kt", "*", "*_kernel_stats.csv")))[-1:]:
     print("\n## kernel trace --stats (per kernel: calls, total ms, average us, % of GPU time)")
     for r in csv.DictReader(open(f)):
         if float(r["Percentage"]) < 0.05: continue
@@ -22,6 +25,7 @@ for f in glob.glob(os.path.join(d, "*", "*", "*_counter_collection.csv")):
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]] += 1
         meta[k] = (r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"])
 print("\n## PMC counters, mean per dispatch (separate --pmc passes)")
+traffic = {}
 for k in sorted(agg):
     m = meta[k]
     print("\n%s  [wg %s, LDS %s B, VGPR %s, SGPR %s, scratch %s]" % ((k,) + m))
@@ -38,3 +42,10 @@ for k in sorted(agg):
         print("    -> HBM-side read  : FETCH_SIZE %.1f KiB raw; x2 gfx950 correction for wide coalesced streams = %.3f MB" % (g("FETCH_SIZE"), 2 * g("FETCH_SIZE") * 1024 / 1e6))
     if g("WRITE_SIZE") is not None:
         print("    -> HBM-side write : WRITE_SIZE %.1f KiB = %.3f MB" % (g("WRITE_SIZE"), g("WRITE_SIZE") * 1024 / 1e6))
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        traffic[k] = {"read_bytes": 2 * g("FETCH_SIZE") * 1024, "write_bytes": g("WRITE_SIZE") * 1024,
+                      "dispatches": calls[k]["FETCH_SIZE"]}
+if len(sys.argv) > 2:
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of scripts/profile_gpu.sh; "
+                         "FETCH_SIZE doubled (gfx950), mean per dispatch", "kernels": traffic},
+              open(sys.argv[2], "w"), indent=1)
