@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pt-spp", type=int, default=32, help="spp of the path-tracing section (whole job)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--workload", choices=("cornell", "mesh1m"), default="cornell",
+                    help="cornell = BASELINE.json configs[1] (the headline); mesh1m = SURVEY.md C4, three "
+                         "displaced icospheres (983 052 triangles) inside the Cornell walls")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -66,8 +69,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    scene = ra.HostScene.load_config(os.path.join(ROOT, "Data", "Config_Glossy1024.xml"))
-    cam = scene.camera()
+    if args.workload == "cornell":
+        scene = ra.HostScene.load_config(os.path.join(ROOT, "Data", "Config_Glossy1024.xml"))
+        cam = scene.camera()
+        scene_name = "BallsWithGlossyWalls"
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import meshgen  # procedural mesh generator (not the oracle)
+        scene = meshgen.mesh_scene(7)
+        cam = ra.make_camera(1024, 1024, 700)
+        scene_name = "DisplacedIcospheres(level 7 x3: diffuse / glossy 5 / glass 1.5)"
     dev = ra.Device(device=local)
     dev.upload(scene.describe())
     wh = cam.width * cam.height
@@ -173,9 +184,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "cornell_closest_hit_16Mi: BallsWithGlossyWalls (1932 tris, %d nodes), 1024x1024; "
+                "workload": "%s_closest_hit_16Mi: %s (%d tris, %d nodes), 1024x1024; "
                             "%d camera rays (mode 0) + %d secondary rays of bounce depth 1-3 (mode 2, "
-                            "NoSelfIntersection) per GPU per step, resident in HBM" % (scene.n_nodes, n_pri, n_sec),
+                            "NoSelfIntersection) per GPU per step, resident in HBM" % (args.workload, scene_name, scene.n_tris,
+                                                                                     scene.n_nodes, n_pri, n_sec),
                 "rays_per_gpu_per_step": n_rays,
                 "hit_rate": round(hit_rate, 4),
                 "box_tests_per_ray": round((pb + sb) / n_rays, 3),
@@ -194,7 +206,7 @@ def main():
         # same command (profiles/, scripts/profile_gpu.sh); null when that profile is of another batch
         traffic_bytes, traffic_src = None, None
         tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_current_traffic.json")
-        if os.path.exists(tj) and n_sec == 12582912:
+        if os.path.exists(tj) and n_sec == 12582912 and args.workload == "cornell":
             k = json.load(open(tj))["kernels"].get("k_intersect<2, false, false>")
             if k:
                 traffic_bytes = int(k["read_bytes"] + k["write_bytes"])
@@ -219,7 +231,7 @@ def main():
             "metric": "path_traced_Msamples_per_s",
             "value": round(wh * pt_spp / pt_elapsed / 1e6, 2),
             "unit": "Msamples/s",
-            "workload": "BallsWithGlossyWalls 1024x1024, %d spp whole job, maxDepth 20, sample-sharded x%d%s"
+            "workload": scene_name + " 1024x1024, %d spp whole job, maxDepth 20, sample-sharded x%d%s"
                         % (pt_spp, world, ", RCCL reduce of 12 MiB fp32 sums" if world > 1 else ""),
             "Mrays_per_s": round(pt_rays / pt_elapsed / 1e6, 2),
             "rays_per_sample": round(pt_rays / (wh * pt_spp), 3),

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -292,12 +293,6 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
             }
     // breadth-first child pairs
     if (T > (1 << 24)) return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: more than 2^24 triangles");
-    auto link_of_leaf = [&](int i, int* out) -> bool {
-        int b = s->node_leaf_begin[i], cnt = s->node_leaf_end[i] - b;
-        if (cnt > 127) return false;
-        *out = ~(int)((uint32_t)b | ((uint32_t)cnt << 24));
-        return true;
-    };
     std::vector<int> order;  // inner nodes in BFS order; pair id = position
     std::vector<int> pair_of(N, -1);
     if (s->node_right[0] >= 0) {
@@ -313,29 +308,60 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
             }
     }
     std::vector<PairRec> pairs(std::max<size_t>(order.size(), 1));
-    auto child_rec = [&](int c, float4* lo, float4* hi) -> bool {
+    memset(pairs.data(), 0, sizeof(PairRec) * pairs.size());
+    // A leaf link holds at most 127 triangles. The reference's build leaves larger leaves where no
+    // split separates the triangles (a fan around one vertex). Such a leaf becomes a small subtree
+    // of synthetic pairs whose children all carry the leaf's own box: the box test on them repeats
+    // the leaf's test bit for bit and slot order is kept, so the answer is unchanged.
+    int extra_depth = 0;
+    std::function<int(int, int, int, int)> range_link = [&](int c, int b, int e, int level) -> int {
+        if (e - b <= 127) {
+            extra_depth = std::max(extra_depth, level);
+            return ~(int)((uint32_t)b | ((uint32_t)(e - b) << 24));
+        }
+        const int mid = b + (e - b) / 2;
+        const size_t q = pairs.size();
+        pairs.push_back(PairRec{});
+        const int ll = range_link(c, b, mid, level + 1), lr = range_link(c, mid, e, level + 1);
+        const float* mn = s->node_min + 3 * c;
+        const float* mx = s->node_max + 3 * c;
+        int flat = (mn[0] == mx[0]) | (mn[1] == mx[1]) | (mn[2] == mx[2]);
+        float fl, fr, fn;
+        memcpy(&fl, &ll, 4);
+        memcpy(&fr, &lr, 4);
+        memcpy(&fn, &flat, 4);
+        pairs[q].llo = make_float4(mn[0], mn[1], mn[2], fl);
+        pairs[q].rlo = make_float4(mn[0], mn[1], mn[2], fr);
+        pairs[q].lhi = pairs[q].rhi = make_float4(mx[0], mx[1], mx[2], fn);
+        return (int)q;
+    };
+    auto child_rec = [&](int c, float4* lo, float4* hi) {
         int lk;
         if (s->node_right[c] >= 0) lk = pair_of[c];
-        else if (!link_of_leaf(c, &lk)) return false;
+        else lk = range_link(c, s->node_leaf_begin[c], s->node_leaf_end[c], 0);
         const float* mn = s->node_min + 3 * c;
         const float* mx = s->node_max + 3 * c;
         int flat = (mn[0] == mx[0]) | (mn[1] == mx[1]) | (mn[2] == mx[2]);
         float fl, fn;
         memcpy(&fl, &lk, 4);
         memcpy(&fn, &flat, 4);
-        *lo = make_float4(s->node_min[3 * c], s->node_min[3 * c + 1], s->node_min[3 * c + 2], fl);
-        *hi = make_float4(s->node_max[3 * c], s->node_max[3 * c + 1], s->node_max[3 * c + 2], fn);
-        return true;
+        *lo = make_float4(mn[0], mn[1], mn[2], fl);
+        *hi = make_float4(mx[0], mx[1], mx[2], fn);
     };
-    memset(pairs.data(), 0, sizeof(PairRec) * pairs.size());
     for (size_t q = 0; q < order.size(); q++) {
         int i = order[q];
-        if (!child_rec(i + 1, &pairs[q].llo, &pairs[q].lhi) || !child_rec(s->node_right[i], &pairs[q].rlo, &pairs[q].rhi))
-            return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: a leaf holds more than 127 triangles");
+        float4 a0, a1, b0, b1;  // (pairs may grow inside child_rec: no references into it here)
+        child_rec(i + 1, &a0, &a1);
+        child_rec(s->node_right[i], &b0, &b1);
+        pairs[q].llo = a0;
+        pairs[q].lhi = a1;
+        pairs[q].rlo = b0;
+        pairs[q].rhi = b1;
     }
     float4 root_lo, root_hi;
-    if (!child_rec(0, &root_lo, &root_hi))
-        return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: a leaf holds more than 127 triangles");
+    child_rec(0, &root_lo, &root_hi);
+    depth += extra_depth;
+    if (depth > 62) return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: tree deeper than 62 levels");
     std::vector<TriRec> tris(T);
     std::vector<VnRec> vns(T);
     for (int k = 0; k < T; k++) {

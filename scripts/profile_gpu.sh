@@ -9,7 +9,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps $STEPS --warmup 1 --no-cpu --pt-spp 8"
+EXTRA=${3:-}
+CMD="python3 $ROOT/bench.py --steps $STEPS --warmup 1 --no-cpu --pt-spp 8 $EXTRA"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $CMD > $OUT/kt.log 2>&1 || { echo "kernel trace failed"; tail -5 $OUT/kt.log; exit 1; }
 echo "kernel trace done"
 pass() {

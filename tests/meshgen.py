@@ -125,6 +125,29 @@ def mesh_scene(level, seed=7, smooth=True):
                                     m["tri_vn"] if smooth else None)
 
 
+def fan_scene(n_fan=300, with_wall=True):
+    """A fan of n_fan triangles around one apex that is the minimum corner of the fan: every median
+    split sends all of them left (a triangle goes left if ANY vertex is <= the split), so the
+    reference's build leaves them in ONE leaf (KDTree.cpp:199-203)."""
+    ang = np.linspace(0.0, 0.5 * np.pi, n_fan + 1)
+    ring = np.stack([0.1 + 0.8 * np.cos(ang), 0.1 + 0.8 * np.sin(ang), 0.3 + 0.2 * np.sin(3 * ang)], axis=1)
+    v = np.concatenate([np.array([[-0.9, -0.9, -0.9]]), ring])
+    f = np.stack([np.zeros(n_fan, np.int64), np.arange(1, n_fan + 1), np.arange(2, n_fan + 2)], axis=1)
+    parts = [(v, f, _obj(ra.OBJ_DIFFUSE, (0.7, 0.7, 0.3), has_vn=0))]
+    if with_wall:
+        qv, qf, _ = _quad((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1), (-1, 0, 0))
+        parts.append((qv, qf, _obj(ra.OBJ_DIFFUSE, (0.5, 0.5, 0.5), has_vn=0)))
+    verts, tris, tri_obj, objects, off = [], [], [], [], 0
+    for oi, (pv, pf, ob) in enumerate(parts):
+        verts.append(pv)
+        tris.append(pf + off)
+        tri_obj.append(np.full(len(pf), oi, np.int32))
+        objects.append(ob)
+        off += len(pv)
+    return ra.HostScene.from_arrays(np.concatenate(verts).astype(np.float32), np.concatenate(tris).astype(np.uint32),
+                                    np.concatenate(tri_obj), np.array(objects, ra.OBJECT_DTYPE), None)
+
+
 def random_rays(n, seed, n_objects, inside_obj=-1):
     """half camera-like rays from (0,0,2), half interior rays; plus packed ids for mode 2"""
     rng = np.random.default_rng(seed)

@@ -93,6 +93,27 @@ def test_flat_shaded_mesh(gpu, ra, orc):
     s.close()
 
 
+@pytest.mark.parametrize("with_wall", [True, False])
+def test_oversized_leaf(gpu, ra, orc, with_wall):
+    """A leaf of 300 triangles (the reference's build cannot split a fan around its minimum corner)
+    is more than one leaf link holds: the upload hangs it under synthetic same-box pairs. Also the
+    case where that leaf is the root."""
+    s = meshgen.fan_scene(300, with_wall)
+    begin, end = s.tree()["leaf_begin"], s.tree()["leaf_end"]
+    assert (end - begin).max() >= 300
+    S = orc.OracleScene(s.raw())
+    gpu.upload(s.describe())
+    o, d, aux = meshgen.random_rays(100000, 45, s.n_objects)
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_NO_SELF, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = S.intersect(o, d, a, mode, threads=16)
+        m, ex = _check(tg, ig, tc, ic, "fan mode %d" % mode)
+        assert m == 1.0 and ex == 1.0
+    assert (ic >= 0).mean() > 0.1
+    S.close()
+    s.close()
+
+
 def test_edge_cases(cornell_dev, cornell, cornell_oracle, ra):
     # empty batch
     t, i = cornell_dev.intersect(np.zeros((3, 0), np.float32), np.zeros((3, 0), np.float32))
