@@ -70,6 +70,20 @@ typedef struct MirtObject {
     float   g;             /* VPM Henyey-Greenstein g                                        */
 } MirtObject;
 
+/* One object's OWN tree (Scene::buildObjKDTrees, Scene.cpp:287-320), same layout as the scene
+ * tree; needed for volumetric objects only, which Scene::findInsideObject (Scene.cpp:354-390)
+ * queries one by one. slot_tid holds triangle ids LOCAL to the object.                          */
+typedef struct MirtObjTree {
+    int32_t  object;                /* index into MirtSceneDesc.objects                       */
+    int32_t  n_nodes;
+    const float*   node_min;
+    const float*   node_max;
+    const int32_t* node_right;
+    const int32_t* node_leaf_begin;
+    const int32_t* node_leaf_end;
+    const int32_t* slot_tid;        /* [objects[object].tri_count]                            */
+} MirtObjTree;
+
 /* Flattened scene: what KDTree::serializeForGPU (KDTree.cpp:346-383) + Scene::buildKDTree
  * (Scene.cpp:248-275) hand to IntersectionGPU::loadKDTreeToShader (IntersectionGPU.cpp:243-255),
  * with integers kept as integers and the data the CPU hit predicate needs added.
@@ -80,7 +94,8 @@ typedef struct MirtObject {
  *   per global triangle id: world-space corner positions, owning object, local triangle id and
  *              world-space (normal-matrix transformed, not normalised) corner normals.          */
 typedef struct MirtSceneDesc {
-    uint32_t struct_size;           /* sizeof(MirtSceneDesc), for versioning                  */
+    uint32_t struct_size;           /* sizeof(MirtSceneDesc), for versioning: a caller built
+                                       against the shorter struct (no obj_trees) still works  */
     int32_t  n_nodes;
     const float*   node_min;        /* [n_nodes*3]                                            */
     const float*   node_max;        /* [n_nodes*3]                                            */
@@ -96,6 +111,9 @@ typedef struct MirtSceneDesc {
                                        no object has has_vn                                    */
     int32_t  n_objects;
     const MirtObject* objects;      /* [n_objects]                                            */
+    int32_t  n_obj_trees;           /* one per MIRT_OBJ_VPM object (required for rendering
+                                       scenes that hold one; closest-hit queries do not use them) */
+    const MirtObjTree* obj_trees;   /* [n_obj_trees]                                          */
 } MirtSceneDesc;
 
 /* Pinhole camera; fields as Camera.h:13-21 (sightDist is an unsigned int there). */

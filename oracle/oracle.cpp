@@ -7,7 +7,8 @@
 //   flatten         KDTree.cpp:346-383      predicate    NoSelfIntersectionCondition.cpp:12-27
 //   normals/frames  SimpleShape.cpp:300-339, LocalFrame.h:14-28
 //   materials       DiffuseMaterial.cpp:4-76, GlossyMaterial.cpp:4-56, RefractiveMaterial.cpp:4-104,
-//                   SceneEmissiveObject.cpp:4-19
+//                   SceneEmissiveObject.cpp:4-19, SceneVPMObject.cpp:4-237 (homogeneous medium),
+//                   Scene.cpp:287-320, 354-390 (per-object trees, findInsideObject)
 //   path sampling   MCRenderer.cpp:149-224  accumulation PathTracer.cpp:23-42
 //   camera          Camera.cpp:4-48,60-78,92-97
 // The one deliberate difference: the reference's global MT19937 (RandGenerator.cpp:9, racy under
@@ -114,6 +115,7 @@ struct OrcScene {
     std::vector<V3> triVn;  // 3 per triangle, may be empty
     std::vector<OrcObject> objects;
     Node* root = nullptr;
+    std::vector<Node*> objRoots;  // Scene::objKDTrees (Scene.cpp:287-320), volumetric objects only
     // flattened view (pre-order) used by the ordered-traversal restatement
     std::vector<V3> fmin, fmax;
     std::vector<int32_t> fright, fbegin, fend, slotTid;
@@ -523,6 +525,7 @@ struct Tracer {
         const OrcObject& o = S.objects[r.insideObject];
         if (o.type == ORC_REFRACTIVE)
             return V3(powf(o.decay[0], dist), powf(o.decay[1], dist), powf(o.decay[2], dist));
+        if (o.type == ORC_VPM) return vpmTransmittance(o, dist);  // SceneVPMObject.cpp:235-237
         return V3(1, 1, 1);
     }
     bool emissive(int obj) const { return obj >= 0 && S.objects[obj].type == ORC_EMISSIVE; }
@@ -544,9 +547,29 @@ struct Tracer {
         return res;
     }
 
-    // Scene::findInsideObject (Scene.cpp:354-390): only volumetric objects count. The homogeneous
-    // medium (config C5) is not restated yet, so there are none.
-    int findInsideObject(const PRay&, int) const { return -1; }
+    // Scene::findInsideObject (Scene.cpp:354-390): the last volumetric object whose own tree is
+    // hit from inside (normal along the ray) both backwards and forwards
+    int findInsideObject(const PRay& ray, int currentObject) const {
+        KRay front, back;
+        front.direction = ray.direction;
+        front.origin = ray.origin;
+        back.direction = -ray.direction;
+        back.origin = ray.origin;
+        for (int i = (int)S.objects.size() - 1; i >= 0; i--) {
+            if (currentObject == i || S.objects[i].type != ORC_VPM || !S.objRoots[i]) continue;
+            unsigned tid = 0;
+            float dist = nodeIntersect(S, back, S.objRoots[i], tid, nullptr, nullptr);
+            if (dist < 1e-6f) continue;
+            V3 normal = worldNormal(S, tid, back.origin + back.direction * dist);
+            if (dot(normal, back.direction) < 1e-6f) continue;
+            dist = nodeIntersect(S, front, S.objRoots[i], tid, nullptr, nullptr);
+            if (dist < 1e-6f) continue;
+            normal = worldNormal(S, tid, front.origin + front.direction * dist);
+            if (dot(normal, front.direction) < 1e-6f) continue;
+            return i;
+        }
+        return -1;
+    }
 
     // DiffuseMaterial.cpp:4-76
     PRay scatterDiffuse(int object, const PRay& in, Stream& rng) const {
@@ -734,6 +757,199 @@ struct Tracer {
         return out;
     }
 
+    // ---- homogeneous medium, SceneVPMObject.h:22-47 / SceneVPMObject.cpp:4-233 --------------------
+    static float lumY(const V3& c) { return 0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2]; }
+    static V3 vpmSigmaT(const OrcObject& o) {  // setSigma: dt = ds + da
+        return V3(o.sigma_s[0] + o.sigma_a[0], o.sigma_s[1] + o.sigma_a[1], o.sigma_s[2] + o.sigma_a[2]);
+    }
+    static V3 vpmTransmittance(const OrcObject& o, float dist) {
+        V3 dt = vpmSigmaT(o), tr;
+        for (int i = 0; i < 3; i++) tr[i] = std::exp(-dt[i] * dist);
+        return tr;
+    }
+    static float vpmPMedium(const OrcObject& o, float s) {
+        V3 dt = vpmSigmaT(o), pm;
+        for (int i = 0; i < 3; i++) pm[i] = dt[i] * std::exp(-dt[i] * s);
+        return lumY(pm);
+    }
+    static float vpmPSurface(const OrcObject& o, float d) { return lumY(vpmTransmittance(o, d)); }
+    // HGPhaseFunc.h:11-17 and HGPhaseSampler.h:63-69 (the same expression)
+    static float hgValue(float g, float cosTheta) {
+        float temp = 1 + g * g - 2 * g * cosTheta;
+        return float(1 / (4 * REF_PI) * (1 - g * g) / (temp * std::sqrt(temp)));
+    }
+    // HGPhaseSampler.h:13-34 (right-handed frame variant, the one that returns)
+    static V3 hgSample(float g, const LocalFrame& lf, Stream& rng) {
+        float e1 = rng.genFloat(), e2 = rng.genFloat();
+        float cosTheta;
+        if (std::abs(g) < 1e-5f) {
+            cosTheta = 1 - 2 * e1;
+        } else {
+            float sqrTerm = (1 - g * g) / (1 - g + 2 * g * e1);
+            cosTheta = (1 + g * g - sqrTerm * sqrTerm) / (2 * g);
+        }
+        float sinTheta = std::sqrt(1 - cosTheta * cosTheta);
+        float sinPhi = float(std::sin(2.0 * REF_PI * e2));
+        float cosPhi = float(std::cos(2.0 * REF_PI * e2));
+        return lf.toWorld(V3(sinTheta * cosPhi, cosTheta, sinTheta * sinPhi));
+    }
+    // the Fresnel split shared by "go in" and "go out" (SceneVPMObject.cpp:23-86, 151-213); returns
+    // false on total internal reflection
+    struct Fresnel {
+        V3 reflDir, refrDir;
+        float er, p;
+        bool total;
+    };
+    Fresnel fresnel(const V3& normal, const V3& inDir, float current_n, float next_n) const {
+        Fresnel f;
+        f.reflDir = -dot(normal, inDir) * normal * 2 + inDir;
+        normalize(f.reflDir);
+        float theta = std::acos(dot(inDir, normal));
+        float sin_phi = current_n / next_n * std::sin(theta);
+        f.total = sin_phi >= 1;
+        f.er = f.p = 0;
+        if (f.total) return f;
+        float phi = std::asin(sin_phi);
+        if (theta > REF_PI / 2) phi = REF_PI - phi;
+        V3 axis = cross(normal, inDir);
+        normalize(axis);
+        f.refrDir = rotate(axis, phi, normal);
+        normalize(f.refrDir);
+        float cos_theta = std::abs(std::cos(theta));
+        float cos_phi = std::abs(std::cos(phi));
+        float esr = powf(std::abs(current_n * cos_theta - next_n * cos_phi) /
+                             (current_n * cos_theta + next_n * cos_phi), 2);
+        float epr = powf(std::abs(next_n * cos_theta - current_n * cos_phi) /
+                             (next_n * cos_theta + current_n * cos_phi), 2);
+        f.er = (esr + epr) * 0.5f;
+        f.p = clampf(f.er, 0.f, 1.f);
+        return f;
+    }
+    PRay scatterVPM(int object, const PRay& in, Stream& rng) const {
+        const OrcObject& o = S.objects[object];
+        PRay out;
+        // HomoMediaDistSampler.h:9-11 (drawn before the case split, SceneVPMObject.cpp:8-9)
+        float sampDist = float(-std::log(1.0 - rng.genFloat()) / lumY(vpmSigmaT(o)));
+        bool go_in_vol = (in.intersectObject == object) && (in.insideObject != object);
+        bool be_in_vol = (in.insideObject == object);
+        bool out_of_vol = (sampDist >= in.intersectDist);
+        if (go_in_vol) {
+            V3 position = in.origin + in.direction * in.intersectDist;
+            LocalFrame lf;
+            lf.buildFromNormal(objNormal(in.intersectObject, in.intersectObjectTriangleID, position));
+            V3 normal = lf.n;
+            out.origin = position;
+            out.direction = in.direction;
+            float current_n = in.insideObject >= 0 ? refrCoeff(in.insideObject) : 1;
+            float next_n = refrCoeff(object);
+            Fresnel f = fresnel(normal, in.direction, current_n, next_n);
+            out.intersectObject = -1;
+            out.color = V3(1, 1, 1);
+            out.directionProb = 1;
+            out.contactObject = object;
+            out.contactObjectTriangleID = in.intersectObjectTriangleID;
+            if (f.total) {
+                out.direction = f.reflDir;
+                out.insideObject = in.insideObject;
+                out.color = out.color / cosineTerm(out);
+            } else {
+                out.direction = f.refrDir;
+                if (rng.genFloat() < f.p) {
+                    out.direction = f.reflDir;
+                    out.color = out.color * (f.er / cosineTerm(out));
+                    out.directionProb = f.p;
+                    out.insideObject = in.insideObject;
+                } else {
+                    out.color = out.color * ((1 - f.er) / cosineTerm(out));
+                    out.directionProb = 1 - f.p;
+                    out.contactObject = out.insideObject = object;
+                }
+                normalize(out.direction);
+            }
+            return out;
+        }
+        if (be_in_vol && !out_of_vol) {
+            LocalFrame lf;
+            lf.buildFromNormal(in.direction);
+            out.origin = in.origin + in.direction * sampDist;
+            out.direction = hgSample(o.g, lf, rng);
+            float ph = hgValue(o.g, dot(in.direction, out.direction));
+            out.color = V3(ph, ph, ph);
+            out.insideObject = object;
+            out.contactObjectTriangleID = in.intersectObjectTriangleID;
+            V3 ds(o.sigma_s[0], o.sigma_s[1], o.sigma_s[2]);
+            float albedo = lumY(ds) / lumY(vpmSigmaT(o));
+            float rander = rng.genFloat();
+            if (rander < albedo) {
+                out.contactObject = -1;
+                float oPdfW = hgValue(o.g, dot(lf.n, out.direction));
+                out.directionProb = albedo * oPdfW;
+                out.originProb = vpmPMedium(o, sampDist);
+                out.color = out.color * ds;
+            } else {
+                out.direction = V3(0, 0, 0);
+                out.color = V3(0, 0, 0);
+                out.directionProb = 1;
+                out.originProb = vpmPMedium(o, sampDist);
+                out.insideObject = object;
+                out.contactObject = -1;
+            }
+            return out;
+        }
+        if (be_in_vol && out_of_vol) {
+            out = in;
+            out.direction = in.direction;
+            out.origin = in.origin + in.intersectDist * in.direction;
+            out.contactObject = in.intersectObject;
+            out.contactObjectTriangleID = in.intersectObjectTriangleID;
+            out.insideObject = object;
+            out.directionProb = 1;
+            out.color = V3(1, 1, 1);
+            bool going_out = (in.intersectObject == object);
+            if (going_out) {
+                LocalFrame lf;
+                lf.buildFromNormal(objNormal(in.intersectObject, in.intersectObjectTriangleID, out.origin));
+                V3 normal = lf.n;
+                int outSide = findInsideObject(out, object);
+                float current_n = refrCoeff(object);
+                float next_n = outSide >= 0 ? refrCoeff(outSide) : 1;
+                Fresnel f = fresnel(normal, in.direction, current_n, next_n);
+                out.intersectObject = -1;
+                out.originProb = vpmPSurface(o, in.intersectDist);
+                if (f.total) {
+                    out.direction = f.reflDir;
+                    out.insideObject = in.insideObject;
+                    out.contactObject = object;
+                    out.color = out.color / cosineTerm(out);
+                } else {
+                    out.direction = f.refrDir;
+                    if (rng.genFloat() < f.p) {
+                        out.direction = f.reflDir;
+                        out.color = out.color * (f.er / cosineTerm(out));
+                        out.directionProb = f.p;
+                        out.insideObject = in.insideObject;
+                    } else {
+                        out.color = out.color * ((1 - f.er) / cosineTerm(out));
+                        out.directionProb = 1 - f.p;
+                        out.insideObject = outSide;
+                    }
+                    normalize(out.direction);
+                }
+            } else {
+                out.contactObject = -1;
+                out.intersectDist = 0;
+                if (in.intersectObject >= 0) out = scatter(in.intersectObject, out, rng);
+                out.originProb *= vpmPSurface(o, in.intersectDist);
+            }
+            return out;
+        }
+        // (the reference falls off the end of the function here: undefined; the path is ended)
+        out.direction = V3(0, 0, 0);
+        out.color = V3(0, 0, 0);
+        out.origin = in.origin;
+        return out;
+    }
+
     // SceneObject.cpp:366-373 (one material per object; the rand() it burns feeds nothing)
     PRay scatter(int object, const PRay& in, Stream& rng) const {
         switch (S.objects[object].type) {
@@ -741,6 +957,7 @@ struct Tracer {
             case ORC_GLOSSY: return scatterGlossy(object, in, rng);
             case ORC_REFRACTIVE: return scatterRefractive(object, in, rng);
             case ORC_EMISSIVE: return scatterEmissive(object, in);
+            case ORC_VPM: return scatterVPM(object, in, rng);
             default: {
                 PRay dead;  // unsupported kind: terminate the path with zero weight
                 dead.direction = V3(0, 0, 0);
@@ -904,12 +1121,24 @@ OrcScene* orc_scene_create(int32_t n_verts, const float* verts, int32_t n_tris, 
     splitBest(*S, S->root, 0, md);
     S->depth = md;
     if (n_tris > 0) flattenNode(*S, S->root);
+    // Scene::buildObjKDTrees (Scene.cpp:287-320): one tree per object over that object's own
+    // triangles; only the volumetric ones are ever queried (Scene.cpp:369)
+    S->objRoots.assign(n_objects, nullptr);
+    for (int oi = 0; oi < n_objects; oi++) {
+        if (objects[oi].type != ORC_VPM) continue;
+        Node* r = new Node;
+        for (int t = 0; t < objects[oi].tri_count; t++) r->triangleIndices.push_back(objects[oi].tri_begin + t);
+        int d2 = 0;
+        splitBest(*S, r, 0, d2);
+        S->objRoots[oi] = r;
+    }
     return S;
 }
 
 void orc_scene_destroy(OrcScene* s) {
     if (!s) return;
     destroyNode(s->root);
+    for (Node* r : s->objRoots) destroyNode(r);
     delete s;
 }
 
@@ -1099,6 +1328,17 @@ int32_t orc_trace_path(const OrcScene* s, const OrcCamera* cam, uint32_t pixel, 
         o[9] = path[i].directionProb;
     }
     return n;
+}
+
+int32_t orc_find_inside(const OrcScene* s, const float o[3], const float d[3], int32_t current) {
+    OrcCamera cam;
+    memset(&cam, 0, sizeof cam);
+    cam.focus[2] = -1;
+    Tracer tr(*s, cam, 0);
+    PRay r;
+    r.origin = V3(o[0], o[1], o[2]);
+    r.direction = V3(d[0], d[1], d[2]);
+    return tr.findInsideObject(r, current);
 }
 
 }  // extern "C"

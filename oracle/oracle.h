@@ -99,6 +99,10 @@ void orc_render_pt(const OrcScene* s, const OrcCamera* cam, uint32_t spp_begin, 
 int32_t orc_trace_path(const OrcScene* s, const OrcCamera* cam, uint32_t pixel, uint32_t sample,
                        uint32_t max_depth, uint32_t seed, float* verts, int32_t cap, float rgb[3]);
 
+/* Scene::findInsideObject (Scene.cpp:354-390) for one ray; current = object to skip or -1.
+ * Returns the object index or -1. */
+int32_t orc_find_inside(const OrcScene* s, const float o[3], const float d[3], int32_t current);
+
 #ifdef __cplusplus
 }
 #endif

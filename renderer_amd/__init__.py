@@ -46,7 +46,8 @@ class SceneDesc(C.Structure):
                 ("node_max", C.c_void_p), ("node_right", C.c_void_p), ("node_leaf_begin", C.c_void_p),
                 ("node_leaf_end", C.c_void_p), ("n_tris", C.c_int32), ("slot_tid", C.c_void_p),
                 ("tri_pos", C.c_void_p), ("tri_obj", C.c_void_p), ("tri_local", C.c_void_p),
-                ("tri_vn", C.c_void_p), ("n_objects", C.c_int32), ("objects", C.c_void_p)]
+                ("tri_vn", C.c_void_p), ("n_objects", C.c_int32), ("objects", C.c_void_p),
+                ("n_obj_trees", C.c_int32), ("obj_trees", C.c_void_p)]
 
 
 # every symbol include/mirt.h and include/mirt_host.h declare (checked by the CPU tests)

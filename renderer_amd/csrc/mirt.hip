@@ -32,7 +32,9 @@ struct MirtContext {
     DevObject* d_objs = nullptr;
     DevScene sc{};
     bool has_scene = false;
-    bool has_unsupported = false;  // scene holds an object kind the shade kernel cannot scatter yet
+    bool has_media = false;    // scene holds a homogeneous medium (MIRT_OBJ_VPM)
+    bool media_ready = true;   // ... and every such object came with its own tree
+    VolRoot* d_vols = nullptr;
     int block = 256;
     size_t lds_main = 0;   // the first lds_levels stack levels live in LDS, deeper ones in d_spill
     uint32_t lds_levels = 0;
@@ -156,6 +158,8 @@ static void free_scene(MirtContext* ctx) {
     hipFree(ctx->d_objs);
     hipFree(ctx->d_spill);
     ctx->d_spill = nullptr;
+    hipFree(ctx->d_vols);
+    ctx->d_vols = nullptr;
     ctx->d_tris = nullptr;
     ctx->d_vns = nullptr;
     ctx->d_objs = nullptr;
@@ -206,11 +210,20 @@ int mirt_device_info(MirtContext* ctx, char* buf, size_t buflen) {
     return MIRT_OK;
 }
 
+// A flattened pre-order tree as MirtSceneDesc / MirtObjTree describe it.
+struct TreeView {
+    int N, T;  // nodes, triangle slots
+    const float* mn;
+    const float* mx;
+    const int32_t* right;
+    const int32_t* lbeg;
+    const int32_t* lend;
+};
+
 // Validates the flattened tree (every index a kernel will follow is range-checked here, on the
 // host, so a malformed description cannot fault the GPU) and returns its depth.
-static int validate_tree(const MirtSceneDesc* s, int* depth_out, std::string* why) {
-    const int N = s->n_nodes, T = s->n_tris;
-    std::vector<int> end(N, -1);  // one past the last node of the subtree rooted at i
+static int validate_tree(const TreeView& s, int* depth_out, std::string* why) {
+    const int N = s.N, T = s.T;
     // iterative pre-order walk: (node, depth)
     std::vector<std::pair<int, int>> st;
     st.push_back({0, 0});
@@ -226,9 +239,9 @@ static int validate_tree(const MirtSceneDesc* s, int* depth_out, std::string* wh
         if (i < 0 || i >= N || seen[i]) { *why = "node index out of range or revisited"; return MIRT_E_INVALID; }
         seen[i] = 1;
         maxd = std::max(maxd, d);
-        int r = s->node_right[i];
+        int r = s.right[i];
         if (r < 0) {
-            int b = s->node_leaf_begin[i], e = s->node_leaf_end[i];
+            int b = s.lbeg[i], e = s.lend[i];
             if (b < 0 || e < b || e > T) { *why = "leaf slot range out of bounds"; return MIRT_E_INVALID; }
             if (b != slots_seen) { *why = "leaf slot ranges are not contiguous in pre-order"; return MIRT_E_INVALID; }
             slots_seen = e;
@@ -244,71 +257,39 @@ static int validate_tree(const MirtSceneDesc* s, int* depth_out, std::string* wh
     return MIRT_OK;
 }
 
-int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
-    if (!ctx) return MIRT_E_INVALID;
-    if (!s || s->struct_size != sizeof(MirtSceneDesc))
-        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: bad descriptor / struct_size");
-    if (s->n_nodes <= 0 || s->n_tris <= 0 || s->n_objects <= 0 || !s->node_min || !s->node_max ||
-        !s->node_right || !s->node_leaf_begin || !s->node_leaf_end || !s->slot_tid || !s->tri_pos ||
-        !s->tri_obj || !s->tri_local || !s->objects)
-        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: empty scene or NULL array");
-    if (s->n_objects > MIRT_MAX_OBJECTS)
-        return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: more than 65533 objects");
-    int depth = 0;
-    std::string why;
-    if (validate_tree(s, &depth, &why) != MIRT_OK)
-        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: " + why);
-    if (depth > MIRT_MAX_TREE_DEPTH)
-        return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: tree deeper than MIRT_MAX_TREE_DEPTH");
-    const int N = s->n_nodes, T = s->n_tris;
-    std::vector<char> tid_seen(T, 0);
-    bool any_vn = false, unsupported = false;
-    for (int o = 0; o < s->n_objects; o++) {
-        any_vn |= s->objects[o].has_vn != 0;
-        int ty = s->objects[o].type;
-        if (ty < MIRT_OBJ_DIFFUSE || ty > MIRT_OBJ_VPM)
-            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: unknown object type");
-        unsupported |= ty == MIRT_OBJ_VPM;
-    }
-    if (any_vn && !s->tri_vn)
-        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: has_vn set but tri_vn is NULL");
-    for (int k = 0; k < T; k++) {
-        int g = s->slot_tid[k];
-        if (g < 0 || g >= T || tid_seen[g])
-            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: slot_tid is not a permutation");
-        tid_seen[g] = 1;
-        if (s->tri_obj[g] < 0 || s->tri_obj[g] >= s->n_objects)
-            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: tri_obj out of range");
-    }
-
-    // the facts the slab classifier's error model needs
-    float bound[3] = {0.f, 0.f, 0.f};
-    int fast_ok = 1;
-    for (int i = 0; i < N; i++)
+// every node bound is 0 or in [2^-36, 2^60) (what the slab classifier's error model needs)
+static bool bounds_in_model(const TreeView& s) {
+    for (int i = 0; i < s.N; i++)
         for (int c = 0; c < 3; c++)
-            for (float v : {s->node_min[3 * i + c], s->node_max[3 * i + c]}) {
+            for (float v : {s.mn[3 * i + c], s.mx[3 * i + c]}) {
                 float a = std::fabs(v);
-                if (!(a == 0.f || (a >= 1.4551915e-11f && a < 1.1529215e18f))) fast_ok = 0;  // also NaN/inf
-                if (i == 0 && a > bound[c]) bound[c] = a;
+                if (!(a == 0.f || (a >= 1.4551915e-11f && a < 1.1529215e18f))) return false;  // also NaN/inf
             }
-    // breadth-first child pairs
-    if (T > (1 << 24)) return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: more than 2^24 triangles");
-    std::vector<int> order;  // inner nodes in BFS order; pair id = position
+    return true;
+}
+
+// Appends the tree's child-pair records (breadth-first over its inner nodes) to `pairs`; leaf
+// links address slots slot_base + [begin, end). Returns the root's own record (box + link) and
+// adds the levels that oversized leaves needed to *depth.
+static void append_pairs(const TreeView& s, int slot_base, std::vector<PairRec>& pairs, float4* root_lo,
+                         float4* root_hi, int* depth) {
+    const int N = s.N;
+    const size_t base = pairs.size();
+    std::vector<int> order;  // inner nodes in BFS order; pair id = base + position
     std::vector<int> pair_of(N, -1);
-    if (s->node_right[0] >= 0) {
+    if (s.right[0] >= 0) {
         order.push_back(0);
-        pair_of[0] = 0;
+        pair_of[0] = (int)base;
     }
     for (size_t q = 0; q < order.size(); q++) {
         int i = order[q];
-        for (int c : {i + 1, s->node_right[i]})
-            if (s->node_right[c] >= 0) {
-                pair_of[c] = (int)order.size();
+        for (int c : {i + 1, s.right[i]})
+            if (s.right[c] >= 0) {
+                pair_of[c] = (int)(base + order.size());
                 order.push_back(c);
             }
     }
-    std::vector<PairRec> pairs(std::max<size_t>(order.size(), 1));
-    memset(pairs.data(), 0, sizeof(PairRec) * pairs.size());
+    pairs.resize(base + order.size(), PairRec{});
     // A leaf link holds at most 127 triangles. The reference's build leaves larger leaves where no
     // split separates the triangles (a fan around one vertex). Such a leaf becomes a small subtree
     // of synthetic pairs whose children all carry the leaf's own box: the box test on them repeats
@@ -317,14 +298,14 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     std::function<int(int, int, int, int)> range_link = [&](int c, int b, int e, int level) -> int {
         if (e - b <= 127) {
             extra_depth = std::max(extra_depth, level);
-            return ~(int)((uint32_t)b | ((uint32_t)(e - b) << 24));
+            return ~(int)((uint32_t)(slot_base + b) | ((uint32_t)(e - b) << 24));
         }
         const int mid = b + (e - b) / 2;
         const size_t q = pairs.size();
         pairs.push_back(PairRec{});
         const int ll = range_link(c, b, mid, level + 1), lr = range_link(c, mid, e, level + 1);
-        const float* mn = s->node_min + 3 * c;
-        const float* mx = s->node_max + 3 * c;
+        const float* mn = s.mn + 3 * c;
+        const float* mx = s.mx + 3 * c;
         int flat = (mn[0] == mx[0]) | (mn[1] == mx[1]) | (mn[2] == mx[2]);
         float fl, fr, fn;
         memcpy(&fl, &ll, 4);
@@ -337,10 +318,10 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     };
     auto child_rec = [&](int c, float4* lo, float4* hi) {
         int lk;
-        if (s->node_right[c] >= 0) lk = pair_of[c];
-        else lk = range_link(c, s->node_leaf_begin[c], s->node_leaf_end[c], 0);
-        const float* mn = s->node_min + 3 * c;
-        const float* mx = s->node_max + 3 * c;
+        if (s.right[c] >= 0) lk = pair_of[c];
+        else lk = range_link(c, s.lbeg[c], s.lend[c], 0);
+        const float* mn = s.mn + 3 * c;
+        const float* mx = s.mx + 3 * c;
         int flat = (mn[0] == mx[0]) | (mn[1] == mx[1]) | (mn[2] == mx[2]);
         float fl, fn;
         memcpy(&fl, &lk, 4);
@@ -352,20 +333,127 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         int i = order[q];
         float4 a0, a1, b0, b1;  // (pairs may grow inside child_rec: no references into it here)
         child_rec(i + 1, &a0, &a1);
-        child_rec(s->node_right[i], &b0, &b1);
-        pairs[q].llo = a0;
-        pairs[q].lhi = a1;
-        pairs[q].rlo = b0;
-        pairs[q].rhi = b1;
+        child_rec(s.right[i], &b0, &b1);
+        pairs[base + q].llo = a0;
+        pairs[base + q].lhi = a1;
+        pairs[base + q].rlo = b0;
+        pairs[base + q].rhi = b1;
     }
-    float4 root_lo, root_hi;
-    child_rec(0, &root_lo, &root_hi);
-    depth += extra_depth;
-    if (depth > 62) return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: tree deeper than 62 levels");
-    std::vector<TriRec> tris(T);
-    std::vector<VnRec> vns(T);
+    child_rec(0, root_lo, root_hi);
+    *depth += extra_depth;
+}
+
+int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
+    if (!ctx) return MIRT_E_INVALID;
+    // struct_size versions the descriptor: the form without per-object trees is still accepted
+    const size_t size_v1 = offsetof(MirtSceneDesc, n_obj_trees);
+    if (!s || (s->struct_size != sizeof(MirtSceneDesc) && s->struct_size != size_v1))
+        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: bad descriptor / struct_size");
+    const int n_obj_trees = s->struct_size == sizeof(MirtSceneDesc) ? s->n_obj_trees : 0;
+    const MirtObjTree* obj_trees = n_obj_trees > 0 ? s->obj_trees : nullptr;
+    if (s->n_nodes <= 0 || s->n_tris <= 0 || s->n_objects <= 0 || !s->node_min || !s->node_max ||
+        !s->node_right || !s->node_leaf_begin || !s->node_leaf_end || !s->slot_tid || !s->tri_pos ||
+        !s->tri_obj || !s->tri_local || !s->objects || n_obj_trees < 0 || (n_obj_trees > 0 && !obj_trees))
+        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: empty scene or NULL array");
+    if (s->n_objects > MIRT_MAX_OBJECTS)
+        return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: more than 65533 objects");
+    const TreeView main_tree{s->n_nodes, s->n_tris, s->node_min, s->node_max, s->node_right,
+                             s->node_leaf_begin, s->node_leaf_end};
+    int depth = 0;
+    std::string why;
+    if (validate_tree(main_tree, &depth, &why) != MIRT_OK)
+        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: " + why);
+    const int N = s->n_nodes, T = s->n_tris;
+    std::vector<char> tid_seen(T, 0);
+    bool any_vn = false;
+    int n_vpm = 0;
+    for (int o = 0; o < s->n_objects; o++) {
+        any_vn |= s->objects[o].has_vn != 0;
+        int ty = s->objects[o].type;
+        if (ty < MIRT_OBJ_DIFFUSE || ty > MIRT_OBJ_VPM)
+            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: unknown object type");
+        n_vpm += ty == MIRT_OBJ_VPM;
+        if (s->objects[o].tri_begin < 0 || s->objects[o].tri_count < 0 ||
+            (long long)s->objects[o].tri_begin + s->objects[o].tri_count > T)
+            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: object triangle range out of bounds");
+    }
+    if (any_vn && !s->tri_vn)
+        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: has_vn set but tri_vn is NULL");
     for (int k = 0; k < T; k++) {
         int g = s->slot_tid[k];
+        if (g < 0 || g >= T || tid_seen[g])
+            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: slot_tid is not a permutation");
+        tid_seen[g] = 1;
+        if (s->tri_obj[g] < 0 || s->tri_obj[g] >= s->n_objects)
+            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: tri_obj out of range");
+    }
+    // per-object trees (volumetric objects): validated like the scene tree
+    long long extra_slots = 0;
+    std::vector<int> obj_depth(n_obj_trees, 0);
+    std::vector<TreeView> obj_view(n_obj_trees);
+    int prev_obj = -1;
+    for (int k = 0; k < n_obj_trees; k++) {
+        const MirtObjTree& ot = obj_trees[k];
+        if (ot.object <= prev_obj || ot.object >= s->n_objects)
+            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: obj_trees must be ordered by distinct object index");
+        prev_obj = ot.object;
+        const MirtObject& ob = s->objects[ot.object];
+        if (ot.n_nodes <= 0 || !ot.node_min || !ot.node_max || !ot.node_right || !ot.node_leaf_begin ||
+            !ot.node_leaf_end || !ot.slot_tid || ob.tri_count <= 0)
+            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: empty object tree or NULL array");
+        obj_view[k] = TreeView{ot.n_nodes, ob.tri_count, ot.node_min, ot.node_max, ot.node_right,
+                               ot.node_leaf_begin, ot.node_leaf_end};
+        if (validate_tree(obj_view[k], &obj_depth[k], &why) != MIRT_OK)
+            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: object tree: " + why);
+        std::vector<char> seen(ob.tri_count, 0);
+        for (int q = 0; q < ob.tri_count; q++) {
+            int l = ot.slot_tid[q];
+            if (l < 0 || l >= ob.tri_count || seen[l])
+                return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: object tree slot_tid is not a permutation");
+            seen[l] = 1;
+        }
+        extra_slots += ob.tri_count;
+    }
+    // rendering a scene with a homogeneous medium needs that object's own tree (findInsideObject)
+    bool media_ready = true;
+    for (int o = 0; o < s->n_objects; o++)
+        if (s->objects[o].type == MIRT_OBJ_VPM) {
+            bool found = false;
+            for (int k = 0; k < n_obj_trees; k++) found |= obj_trees[k].object == o;
+            media_ready &= found;
+        }
+
+    // the facts the slab classifier's error model needs
+    float bound[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < 3; c++)
+        for (float v : {s->node_min[c], s->node_max[c]}) bound[c] = std::max(bound[c], std::fabs(v));
+    int fast_ok = bounds_in_model(main_tree) ? 1 : 0;
+    if ((long long)T + extra_slots > (1 << 24))
+        return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: more than 2^24 triangle slots");
+    std::vector<PairRec> pairs;
+    float4 root_lo, root_hi;
+    append_pairs(main_tree, 0, pairs, &root_lo, &root_hi, &depth);
+    if (pairs.empty()) pairs.push_back(PairRec{});
+    // object trees share the pair / triangle arrays; their slots follow the scene's
+    std::vector<VolRoot> vols(n_obj_trees);
+    {
+        int slot_base = T;
+        for (int k = 0; k < n_obj_trees; k++) {
+            // an object's boxes lie inside the scene's root box (same vertices), so `bound` covers them
+            if (!bounds_in_model(obj_view[k])) fast_ok = 0;
+            append_pairs(obj_view[k], slot_base, pairs, &vols[k].lo, &vols[k].hi, &obj_depth[k]);
+            vols[k].object = obj_trees[k].object;
+            vols[k].pad[0] = vols[k].pad[1] = vols[k].pad[2] = 0;
+            depth = std::max(depth, obj_depth[k]);
+            slot_base += s->objects[obj_trees[k].object].tri_count;
+        }
+    }
+    if (depth > MIRT_MAX_TREE_DEPTH)
+        return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: tree deeper than MIRT_MAX_TREE_DEPTH");
+    const size_t TT = (size_t)T + (size_t)extra_slots;
+    std::vector<TriRec> tris(TT);
+    std::vector<VnRec> vns(TT);
+    auto fill_slot = [&](size_t k, int g) {  // slot k holds global triangle g
         const float* p = s->tri_pos + 9 * (size_t)g;
         h3 v0{p[0], p[1], p[2]}, v1{p[3], p[4], p[5]}, v2{p[6], p[7], p[8]};
         // KDTree.cpp:283-284: n = normalize(lines[0] x lines[1])
@@ -386,6 +474,14 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         float fh;
         memcpy(&fh, &hv, 4);
         vns[k].n2 = make_float4(vn ? vn[6] : 0.f, vn ? vn[7] : 0.f, vn ? vn[8] : 0.f, fh);
+    };
+    for (int k = 0; k < T; k++) fill_slot((size_t)k, s->slot_tid[k]);
+    {
+        size_t slot = (size_t)T;
+        for (int k = 0; k < n_obj_trees; k++) {
+            const MirtObject& ob = s->objects[obj_trees[k].object];
+            for (int q = 0; q < ob.tri_count; q++) fill_slot(slot++, ob.tri_begin + obj_trees[k].slot_tid[q]);
+        }
     }
     std::vector<DevObject> objs(s->n_objects);
     for (int o = 0; o < s->n_objects; o++) {
@@ -401,6 +497,11 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         }
         d.coeff = m.coeff;
         d.ior = m.ior;
+        for (int c = 0; c < 3; c++) {
+            d.sigma_s[c] = m.sigma_s[c];
+            d.sigma_t[c] = m.sigma_s[c] + m.sigma_a[c];  // SceneVPMObject.h:82-86: dt = ds + da
+        }
+        d.g = m.g;
     }
 
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -408,11 +509,17 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     free_scene(ctx);
     HIPCHK(ctx, hipMalloc(&ctx->d_pairs, sizeof(PairRec) * pairs.size()));
     HIPCHK(ctx, hipMemcpy(ctx->d_pairs, pairs.data(), sizeof(PairRec) * pairs.size(), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMalloc(&ctx->d_tris, sizeof(TriRec) * (size_t)T));
-    HIPCHK(ctx, hipMalloc(&ctx->d_vns, sizeof(VnRec) * (size_t)T));
+    HIPCHK(ctx, hipMalloc(&ctx->d_tris, sizeof(TriRec) * TT));
+    HIPCHK(ctx, hipMalloc(&ctx->d_vns, sizeof(VnRec) * TT));
     HIPCHK(ctx, hipMalloc(&ctx->d_objs, sizeof(DevObject) * (size_t)s->n_objects));
-    HIPCHK(ctx, hipMemcpy(ctx->d_tris, tris.data(), sizeof(TriRec) * (size_t)T, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(ctx->d_vns, vns.data(), sizeof(VnRec) * (size_t)T, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_tris, tris.data(), sizeof(TriRec) * TT, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_vns, vns.data(), sizeof(VnRec) * TT, hipMemcpyHostToDevice));
+    if (n_obj_trees > 0) {
+        HIPCHK(ctx, hipMalloc(&ctx->d_vols, sizeof(VolRoot) * vols.size()));
+        HIPCHK(ctx, hipMemcpy(ctx->d_vols, vols.data(), sizeof(VolRoot) * vols.size(), hipMemcpyHostToDevice));
+    }
+    ctx->sc.vols = ctx->d_vols;
+    ctx->sc.n_vols = n_obj_trees;
     HIPCHK(ctx, hipMemcpy(ctx->d_objs, objs.data(), sizeof(DevObject) * (size_t)s->n_objects, hipMemcpyHostToDevice));
     for (int c = 0; c < 3; c++) ctx->sc.bound[c] = bound[c];
     ctx->sc.fast_ok = fast_ok;
@@ -454,7 +561,8 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     if (spill_levels)
         HIPCHK(ctx, hipMalloc(&ctx->d_spill, spill_levels * (size_t)ctx->max_blocks * ctx->block * sizeof(uint2)));
     ctx->has_scene = true;
-    ctx->has_unsupported = unsupported;
+    ctx->has_media = n_vpm > 0;
+    ctx->media_ready = media_ready;
     return MIRT_OK;
 }
 
@@ -707,8 +815,12 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
     for (uint32_t depth = 0; depth <= prm->max_depth; depth++) {
         const uint32_t* n_in = depth ? ctx->d_cnt + depth : nullptr;
         uint32_t* n_out = ctx->d_cnt + depth + 1;
-        hipLaunchKernelGGL(k_shade, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in, bound,
-                           *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, depth, prm->max_depth);
+        if (ctx->has_media)
+            hipLaunchKernelGGL(k_shade<true>, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in,
+                               bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, depth, prm->max_depth);
+        else
+            hipLaunchKernelGGL(k_shade<false>, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in,
+                               bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, depth, prm->max_depth);
         HIPCHK(ctx, hipGetLastError());
         depths_run = depth + 1;
         if (depth == prm->max_depth) break;  // nothing survives the depth cap (MCRenderer.cpp:187-191)
@@ -755,10 +867,10 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     if (!ctx) return MIRT_E_INVALID;
     if (!ctx->has_scene) return fail(ctx, MIRT_E_NO_SCENE, "render: no scene uploaded");
     if (!prm) return fail(ctx, MIRT_E_INVALID, "render: params is NULL");
-    if (ctx->has_unsupported)
+    if (ctx->has_media && !ctx->media_ready)
         return fail(ctx, MIRT_E_INVALID,
-                    "render: the scene holds a homogeneous-medium (VPM) object; the shade kernel does "
-                    "not scatter in media yet");
+                    "render: the scene holds a homogeneous medium (MIRT_OBJ_VPM) whose own tree was not "
+                    "uploaded (MirtSceneDesc.obj_trees)");
     DevCamera cam;
     int rc = make_camera(ctx, &prm->camera, &cam);
     if (rc != MIRT_OK) return rc;

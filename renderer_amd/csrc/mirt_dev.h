@@ -50,6 +50,16 @@ struct DevObject {
     float coeff;
     float ior;
     float decay[3];
+    float sigma_s[3];  // homogeneous medium (SceneVPMObject.h:13-14): ds, dt = ds + da, HG g
+    float sigma_t[3];
+    float g;
+    float pad2;
+};
+// root record of one volumetric object's own tree (Scene::objKDTrees, Scene.cpp:287-320):
+// lo.w = bits(link), hi.w = bits(flat), like a PairRec child
+struct VolRoot {
+    float4 lo, hi;
+    int object, pad[3];
 };
 
 struct DevScene {
@@ -58,6 +68,8 @@ struct DevScene {
     const TriRec* tris;
     const VnRec* vns;
     const DevObject* objects;
+    const VolRoot* vols;  // per-object trees of the volumetric objects, ascending object index
+    int n_vols;
     int n_nodes, n_tris, n_objects, depth;
     float bound[3];       // max |coordinate| of the root box per axis
     int fast_ok;          // every node bound is 0 or in [2^-36, 2^60): the slab classifier may be used

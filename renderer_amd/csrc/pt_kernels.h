@@ -152,9 +152,252 @@ __device__ __forceinline__ float vignette_div(const DevCamera& c, uint32_t pixel
     return fabsf(dot3(dir, c.front));
 }
 
+// ---- volumetric objects: Scene::findInsideObject (Scene.cpp:354-390) on the device ---------------
+// Unconditional closest hit inside ONE object's own tree (Scene::objKDTrees[i].intersect). Rare
+// (camera rays and boundary crossings of scenes that hold a medium), so: the reference box test
+// throughout, a private stack, nearer child first with the same pruning / tie rules as k_intersect.
+__device__ inline float trace_object(const DevScene& sc, const VolRoot& R, f3 o, f3 d, int& slot_out) {
+    uint2 stk[MIRT_MAX_TREE_DEPTH + 2];
+    int sp = 0, best_slot = -1;
+    float best = -1.f, thr = __builtin_inff();
+    int link = __float_as_int(R.lo.w);
+    bool has = box_test(R.lo, R.hi, o, d).hit;
+    auto pop = [&]() {
+        has = false;
+        while (sp > 0) {
+            sp--;
+            const uint2 e = stk[sp];
+            if (__uint_as_float(e.y) > thr) continue;
+            link = (int)e.x;
+            has = true;
+            break;
+        }
+    };
+    while (has) {
+        if (link >= 0) {
+            const PairRec P = sc.pairs[link];
+            const BoxHit bl = box_test(P.llo, P.lhi, o, d), br = box_test(P.rlo, P.rhi, o, d);
+            const bool vl = bl.hit && !(bl.lb > thr), vr = br.hit && !(br.lb > thr);
+            const int kl = __float_as_int(P.llo.w), kr = __float_as_int(P.rlo.w);
+            const bool pick_l = vl && (!vr || bl.lb <= br.lb);
+            if (vl && vr) {
+                stk[sp] = make_uint2((uint32_t)(pick_l ? kr : kl), __float_as_uint(pick_l ? br.lb : bl.lb));
+                sp++;
+            }
+            if (vl || vr)
+                link = pick_l ? kl : kr;
+            else
+                pop();
+        } else {
+            const uint32_t v = ~(uint32_t)link;
+            const int beg = (int)(v & 0xFFFFFFu), end = beg + (int)(v >> 24);
+            for (int s = beg; s < end; s++) {
+                const float t = tri_test(sc.tris[s], o, d);
+                if (!(t >= 0.f)) continue;
+                if (!(best_slot < 0 || t < best || (t == best && best_slot < beg))) continue;
+                best = t;
+                best_slot = s;
+                thr = t * 1.0001f + 1e-5f;
+            }
+            pop();
+        }
+    }
+    slot_out = best_slot;
+    return best_slot >= 0 ? best : -1.f;
+}
+
+// the last volumetric object (other than `current`) whose own surface is met from inside both
+// backwards and forwards along the ray; -1 = none
+__device__ inline int find_inside(const DevScene& sc, f3 o, f3 d, int current) {
+    const f3 bd = neg(d);
+    for (int k = sc.n_vols - 1; k >= 0; k--) {
+        const VolRoot R = sc.vols[k];
+        if (R.object == current) continue;
+        int slot = -1;
+        float dist = trace_object(sc, R, o, bd, slot);
+        if (dist < 1e-6f) continue;
+        VnRec V = sc.vns[slot];
+        f3 n = world_normal(sc.tris[slot], V, __float_as_int(V.n2.w) != 0, o + bd * dist);
+        if (dot3(n, bd) < 1e-6f) continue;
+        dist = trace_object(sc, R, o, d, slot);
+        if (dist < 1e-6f) continue;
+        V = sc.vns[slot];
+        n = world_normal(sc.tris[slot], V, __float_as_int(V.n2.w) != 0, o + d * dist);
+        if (dot3(n, d) < 1e-6f) continue;
+        return R.object;
+    }
+    return -1;
+}
+
+// ---- homogeneous medium helpers, SceneVPMObject.h:22-47 ----------------------------------------
+__device__ __forceinline__ float lum_y(f3 c) { return (0.212671f * c.x + 0.715160f * c.y) + 0.072169f * c.z; }
+__device__ __forceinline__ f3 sig_t(const DevObject& o) { return mk3(o.sigma_t[0], o.sigma_t[1], o.sigma_t[2]); }
+__device__ __forceinline__ f3 vpm_transmittance(const DevObject& o, float dist) {
+    return mk3(expf(-o.sigma_t[0] * dist), expf(-o.sigma_t[1] * dist), expf(-o.sigma_t[2] * dist));
+}
+__device__ __forceinline__ float vpm_p_medium(const DevObject& o, float s) {
+    return lum_y(mk3(o.sigma_t[0] * expf(-o.sigma_t[0] * s), o.sigma_t[1] * expf(-o.sigma_t[1] * s),
+                     o.sigma_t[2] * expf(-o.sigma_t[2] * s)));
+}
+__device__ __forceinline__ float vpm_p_surface(const DevObject& o, float d) { return lum_y(vpm_transmittance(o, d)); }
+// HGPhaseFunc.h:11-17 = HGPhaseSampler.h:63-69
+__device__ __forceinline__ float hg_value(float g, float cosTheta) {
+    const float temp = (1.f + g * g) - 2.f * g * cosTheta;
+    return (float)(1.0 / (4.0 * 3.14159265358979) * (double)(1.f - g * g) / (double)(temp * sqrtf(temp)));
+}
+
+// what a scattering event hands to the common tail of k_shade
+struct Scatter {
+    f3 pos;            // the new vertex
+    f3 nd;             // outgoing direction; zero = the path ends here
+    f3 color;
+    float dirProb, originProb;
+    int contact, inside;  // of the outgoing ray
+    bool cos_term;     // the new vertex has a cosine term against `nn` (Ray.cpp:71-78)
+    bool emitted;      // the path ended on an emitter: score it
+    f3 nn;             // contact normal (when cos_term)
+};
+
+// Fresnel split shared by RefractiveMaterial.cpp:48-101 and SceneVPMObject.cpp:23-86, 151-213.
+// `clamp_cos`: the refractive material clamps the cosine before acos, the medium does not;
+// `unit_refl`: the medium normalises the mirror direction before use.
+// Sets nd, dirProb, through and `factor`: on total reflection (total = true) the colour is DIVIDED
+// by factor (the cosine term), otherwise MULTIPLIED by it, exactly as the reference rounds them.
+// Draws one number unless totally reflected.
+__device__ __forceinline__ void fresnel_split(f3 nn, f3 d, float cur_n, float next_n, bool clamp_cos, bool unit_refl,
+                                              bool surface_cos, uint32_t key, uint32_t& ctr, f3& nd,
+                                              float& factor, float& dirProb, bool& through, bool& total) {
+    f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
+    if (unit_refl) refl = normalize3(refl);
+    float c = dot3(d, nn);
+    if (clamp_cos) c = clampf(c, -1.f, 1.f);
+    const float theta = acosf(c);
+    const float sin_phi = cur_n / next_n * sinf(theta);
+    through = false;
+    dirProb = 1.f;
+    auto cosine = [&](f3 dir) {  // Ray::getCosineTerm of the outgoing ray
+        if (!surface_cos) return 1.f;
+        float ct = fabsf(dot3(nn, dir));
+        return ct > 1e-6f ? ct : 1e-6f;
+    };
+    total = sin_phi >= 1.f;
+    if (total) {
+        nd = refl;
+        factor = cosine(nd);
+    } else {
+        float phi = asinf(sin_phi);
+        if ((double)theta > 3.14159265358979 / 2) phi = (float)(3.14159265358979 - (double)phi);
+        const f3 axis = normalize3(cross3(nn, d));
+        const f3 rdir = normalize3(rotate_about(axis, phi, nn));
+        const float cos_t = fabsf(cosf(theta)), cos_p = fabsf(cosf(phi));
+        const float a1 = fabsf(cur_n * cos_t - next_n * cos_p) / (cur_n * cos_t + next_n * cos_p);
+        const float a2 = fabsf(next_n * cos_t - cur_n * cos_p) / (next_n * cos_t + cur_n * cos_p);
+        const float er = (a1 * a1 + a2 * a2) / 2.f;
+        const float p = clampf(er, 0.f, 1.f);
+        if (rng_float(key, ctr) < p) {
+            nd = refl;
+            factor = er / cosine(nd);
+            dirProb = p;
+        } else {
+            nd = rdir;
+            factor = (1.f - er) / cosine(nd);
+            dirProb = 1.f - p;
+            through = true;
+        }
+    }
+    nd = normalize3(nd);
+}
+
+// Material scatter of the object that was HIT (DiffuseMaterial.cpp:4-76, GlossyMaterial.cpp:4-56,
+// RefractiveMaterial.cpp:4-104, SceneEmissiveObject.cpp:4-19). `inside` = the incoming ray's inside
+// object. VOL: the scene holds volumetric objects, so leaving a refractive object asks
+// findInsideObject for the medium outside (RefractiveMaterial.cpp:52-53).
+template <bool VOL>
+__device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const DevObject& ob, int hobj, f3 nn, f3 pos,
+                                                   f3 d, int inside, uint32_t key, uint32_t& ctr) {
+    Scatter r;
+    r.pos = pos;
+    r.nd = mk3(0, 0, 0);
+    r.color = mk3(0, 0, 0);
+    r.dirProb = 1.f;
+    r.originProb = 1.f;
+    r.contact = hobj;
+    r.inside = inside;
+    r.cos_term = true;
+    r.emitted = false;
+    r.nn = nn;
+    const f3 col = mk3(ob.color[0], ob.color[1], ob.color[2]);
+    if (ob.type == MIRT_OBJ_EMISSIVE) {
+        // SceneEmissiveObject.cpp:4-19: the path ends; radiance only from the front side
+        r.color = dot3(d, nn) <= 0.f ? col : mk3(0, 0, 0);
+        r.emitted = true;
+        r.inside = -1;
+    } else if (ob.type == MIRT_OBJ_DIFFUSE) {
+        if (dot3(d, nn) > 0.f) {  // DiffuseMaterial.cpp:35-44: back side passes through
+            r.nd = d;
+            r.color = mk3(1, 1, 1);
+        } else {
+            Frame lf = frame_from_normal(nn);
+            float dx = rng_float(key, ctr), dy = rng_float(key, ctr);
+            f3 dir = to_world(lf, hemi_cos(1.f, dx, dy));
+            float p = max3f(col);
+            if (rng_float(key, ctr) < p) {
+                bool ok = dot3(nn, d) <= 0.f && dot3(nn, dir) >= 0.f;
+                r.color = ok ? div3(col, 3.14159265358979f) : mk3(0, 0, 0);
+                r.dirProb = p * cos_pdf(nn, dir, 1.f);
+                r.nd = dir;
+            }
+        }
+    } else if (ob.type == MIRT_OBJ_GLOSSY) {
+        f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
+        Frame olf = frame_from_normal(refl);
+        float dx = rng_float(key, ctr), dy = rng_float(key, ctr);
+        f3 dir = to_world(olf, hemi_cos(ob.coeff, dx, dy));
+        f3 c = mk3(0, 0, 0);
+        if (dot3(nn, d) <= 0.f && dot3(nn, dir) >= 0.f) {
+            float rd = dot3(refl, dir);
+            if (rd > 0.f) c = col * powf(rd, ob.coeff);
+        }
+        if (len3(c) != 0.f) {
+            float p = max3f(col);
+            if (rng_float(key, ctr) < p) {
+                r.color = c;
+                r.dirProb = cos_pdf(refl, dir, ob.coeff) * p;
+                r.nd = dir;
+            }
+        }
+    } else if (ob.type == MIRT_OBJ_REFRACTIVE) {
+        if (ob.ior < 0.f) {  // mirror
+            f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
+            r.nd = refl;
+            float ct = fabsf(dot3(nn, r.nd));
+            ct = ct > 1e-6f ? ct : 1e-6f;
+            r.color = div3(col, ct);
+        } else {
+            // leaving our own boundary: the medium outside is the enclosing volumetric object
+            int outside = hobj;
+            if (inside == hobj) outside = VOL ? find_inside(sc, pos, d, hobj) : -1;
+            float cur_n = inside >= 0 ? refr_coeff(sc.objects[inside]) : 1.f;
+            float next_n = outside >= 0 ? refr_coeff(sc.objects[outside]) : 1.f;
+            float factor;
+            bool through, total;
+            fresnel_split(nn, d, cur_n, next_n, true, false, true, key, ctr, r.nd, factor, r.dirProb, through, total);
+            // (total reflection divides, the random branches multiply: RefractiveMaterial.cpp:67,90,96)
+            r.color = total ? div3(col, factor) : col * factor;
+            if (through) r.inside = outside;
+        }
+    }
+    return r;
+}
+
 // One bounce for every live path: score emitter hits, scatter, Russian roulette, write the next ray
 // of each surviving path to `out` at a compacted position (wave ballot + block prefix + one atomic
 // per block). Results do not depend on the order of `out` (RNG and radiance slots are keyed by pid).
+// VOL: the scene holds a homogeneous medium (SceneVPMObject.cpp:4-233): the scatter of a path that
+// is inside one is the medium's (MCRenderer.cpp:167-170), camera rays look up their inside object
+// (Camera.cpp:35), and the private stack of trace_object costs scratch memory; scenes without media
+// run the VOL = false instantiation, which has none of it.
+template <bool VOL>
 __global__ void __launch_bounds__(256)
 k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_in, uint32_t n_max,
         PathBuf out, uint32_t* __restrict__ n_out, float* __restrict__ L, uint32_t L_stride,
@@ -179,136 +422,130 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
             key = in.key[i];
             ctr = in.ctr[i];
             pid = in.pid[i];
-            const int inside = unpack_inside(in.ids[i]);
+            int inside = unpack_inside(in.ids[i]);
+            if (VOL && depth == 0) inside = find_inside(sc, o, d, -1);  // Camera.cpp:35
             const TriRec T = sc.tris[slot];
             const VnRec V = sc.vns[slot];
             const int hobj = __float_as_int(V.n0.w);
             const DevObject ob = sc.objects[hobj];
             const f3 pos = o + d * t;
-            // decay along the finished segment, Ray.cpp:66-69 + RefractiveMaterial.h:15
+            const f3 nn = world_normal(T, V, ob.has_vn != 0, pos);
+
+            // whose scatter() runs (MCRenderer.cpp:167-174): the inside object's if there is one; a
+            // refractive inside object hands a hit on another object to that object
+            // (RefractiveMaterial.cpp:42-46)
+            int sobj = inside >= 0 ? inside : hobj;
+            if (VOL && sobj != hobj) {
+                const DevObject so = sc.objects[sobj];
+                if (so.type != MIRT_OBJ_VPM) sobj = hobj;
+            }
+            Scatter sr;
+            if (VOL && sc.objects[sobj].type == MIRT_OBJ_VPM) {
+                // ---- SceneVPMObject::scatter -------------------------------------------------------
+                const DevObject vo = sc.objects[sobj];
+                // HomoMediaDistSampler.h:9-11, drawn before the case split
+                const float u = rng_float(key, ctr);
+                const float samp = (float)(-log(1.0 - (double)u) / (double)lum_y(sig_t(vo)));
+                const bool go_in = (hobj == sobj) && (inside != sobj);
+                const bool be_in = (inside == sobj);
+                const bool out_of_vol = samp >= t;
+                sr.pos = pos;
+                sr.nd = mk3(0, 0, 0);
+                sr.color = mk3(0, 0, 0);
+                sr.dirProb = 1.f;
+                sr.originProb = 1.f;
+                sr.contact = -1;
+                sr.inside = inside;
+                sr.cos_term = false;
+                sr.emitted = false;
+                sr.nn = nn;
+                if (go_in) {
+                    const float cur_n = inside >= 0 ? refr_coeff(sc.objects[inside]) : 1.f;
+                    float factor;
+                    bool through, total;
+                    fresnel_split(nn, d, cur_n, refr_coeff(vo), false, true, false, key, ctr, sr.nd, factor,
+                                  sr.dirProb, through, total);
+                    sr.color = total ? mk3(1, 1, 1) : mk3(factor, factor, factor);  // cosine term is 1
+                    sr.contact = sobj;
+                    if (through) sr.inside = sobj;
+                } else if (be_in && !out_of_vol) {
+                    Frame lf = frame_from_normal(d);
+                    sr.pos = o + d * samp;
+                    // HGPhaseSampler.h:13-34
+                    const float e1 = rng_float(key, ctr), e2 = rng_float(key, ctr);
+                    float cosTheta;
+                    if (fabsf(vo.g) < 1e-5f) {
+                        cosTheta = 1.f - 2.f * e1;
+                    } else {
+                        const float sqrTerm = (1.f - vo.g * vo.g) / ((1.f - vo.g) + 2.f * vo.g * e1);
+                        cosTheta = ((1.f + vo.g * vo.g) - sqrTerm * sqrTerm) / (2.f * vo.g);
+                    }
+                    const float sinTheta = sqrtf(1.f - cosTheta * cosTheta);
+                    const float sinPhi = (float)sin(2.0 * 3.14159265358979 * (double)e2);
+                    const float cosPhi = (float)cos(2.0 * 3.14159265358979 * (double)e2);
+                    const f3 dir = to_world(lf, mk3(sinTheta * cosPhi, cosTheta, sinTheta * sinPhi));
+                    const float ph = hg_value(vo.g, dot3(d, dir));
+                    const f3 ds = mk3(vo.sigma_s[0], vo.sigma_s[1], vo.sigma_s[2]);
+                    const float albedo = lum_y(ds) / lum_y(sig_t(vo));
+                    const float rander = rng_float(key, ctr);
+                    sr.inside = sobj;
+                    sr.originProb = vpm_p_medium(vo, samp);
+                    if (rander < albedo) {
+                        sr.nd = dir;
+                        sr.dirProb = albedo * hg_value(vo.g, dot3(lf.n, dir));
+                        sr.color = mk3(ph, ph, ph) * ds;
+                    }
+                } else if (be_in && out_of_vol) {
+                    if (hobj == sobj) {  // leaving through the medium's own boundary
+                        const int outside = find_inside(sc, pos, d, sobj);
+                        const float next_n = outside >= 0 ? refr_coeff(sc.objects[outside]) : 1.f;
+                        float factor;
+                        bool through, total;
+                        fresnel_split(nn, d, refr_coeff(vo), next_n, false, true, false, key, ctr, sr.nd, factor,
+                                      sr.dirProb, through, total);
+                        sr.color = total ? mk3(1, 1, 1) : mk3(factor, factor, factor);
+                        sr.contact = sobj;
+                        sr.inside = through ? outside : sobj;
+                        sr.originProb = vpm_p_surface(vo, t);
+                    } else {  // a surface inside the medium: that object's scatter, from the hit point
+                        sr = surface_scatter<VOL>(sc, ob, hobj, nn, pos, d, sobj, key, ctr);
+                        sr.originProb = sr.originProb * vpm_p_surface(vo, t);
+                    }
+                }
+            } else {
+                sr = surface_scatter<VOL>(sc, ob, hobj, nn, pos, d, inside, key, ctr);
+            }
+
+            // decay along the finished segment (Ray.cpp:66-69): RefractiveMaterial.h:15 or the
+            // medium's transmittance (SceneVPMObject.cpp:235-237), over the distance between vertices
             if (inside >= 0) {
                 const DevObject io = sc.objects[inside];
                 if (io.type == MIRT_OBJ_REFRACTIVE) {
-                    float dist = len3(pos - o);
-                    thr = thr * mk3(powf(io.decay[0], dist), powf(io.decay[1], dist),
-                                    powf(io.decay[2], dist));
+                    float dist = len3(sr.pos - o);
+                    thr = thr * mk3(powf(io.decay[0], dist), powf(io.decay[1], dist), powf(io.decay[2], dist));
+                } else if (VOL && io.type == MIRT_OBJ_VPM) {
+                    thr = thr * vpm_transmittance(io, len3(sr.pos - o));
                 }
             }
-            const f3 nn = world_normal(T, V, ob.has_vn != 0, pos);
-            const f3 col = mk3(ob.color[0], ob.color[1], ob.color[2]);
-            f3 color = mk3(0, 0, 0);
-            float dirProb = 1.f;
-            int ninside = inside;
-            bool term = true;
-            nd = mk3(0, 0, 0);
-            if (ob.type == MIRT_OBJ_EMISSIVE) {
-                // SceneEmissiveObject.cpp:4-19: the path ends; radiance only from the front side
-                color = dot3(d, nn) <= 0.f ? col : mk3(0, 0, 0);
-                f3 w = div3(color, dirProb);
-                thr = thr * w;
+            // PathTracer.cpp:31: color / directionProb / originProb
+            thr = thr * div3(div3(sr.color, sr.dirProb), sr.originProb);
+            nd = sr.nd;
+            if (sr.emitted) {
                 float vd = vignette_div(cam, pid % ((uint32_t)cam.width * (uint32_t)cam.height));
                 f3 rad = div3(thr, vd);
                 L[pid] = rad.x;
                 L[L_stride + pid] = rad.y;
                 L[2 * L_stride + pid] = rad.z;
-            } else if (ob.type == MIRT_OBJ_DIFFUSE) {
-                if (dot3(d, nn) > 0.f) {  // DiffuseMaterial.cpp:35-44: back side passes through
-                    nd = d;
-                    color = mk3(1, 1, 1);
-                    term = false;
-                } else {
-                    Frame lf = frame_from_normal(nn);
-                    float dx = rng_float(key, ctr), dy = rng_float(key, ctr);
-                    f3 dir = to_world(lf, hemi_cos(1.f, dx, dy));
-                    float p = max3f(col);
-                    if (rng_float(key, ctr) < p) {
-                        bool ok = dot3(nn, d) <= 0.f && dot3(nn, dir) >= 0.f;
-                        color = ok ? div3(col, 3.14159265358979f) : mk3(0, 0, 0);
-                        dirProb = p * cos_pdf(nn, dir, 1.f);
-                        nd = dir;
-                        term = false;
-                    }
-                }
-            } else if (ob.type == MIRT_OBJ_GLOSSY) {
-                f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
-                Frame olf = frame_from_normal(refl);
-                float dx = rng_float(key, ctr), dy = rng_float(key, ctr);
-                f3 dir = to_world(olf, hemi_cos(ob.coeff, dx, dy));
-                f3 c = mk3(0, 0, 0);
-                if (dot3(nn, d) <= 0.f && dot3(nn, dir) >= 0.f) {
-                    float rd = dot3(refl, dir);
-                    if (rd > 0.f) c = col * powf(rd, ob.coeff);
-                }
-                if (len3(c) != 0.f) {
-                    float p = max3f(col);
-                    if (rng_float(key, ctr) < p) {
-                        color = c;
-                        dirProb = cos_pdf(refl, dir, ob.coeff) * p;
-                        nd = dir;
-                        term = false;
-                    }
-                }
-            } else if (ob.type == MIRT_OBJ_REFRACTIVE) {
-                f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
-                term = false;
-                if (ob.ior < 0.f) {  // mirror
-                    nd = refl;
-                    float ct = fabsf(dot3(nn, nd));
-                    ct = ct > 1e-6f ? ct : 1e-6f;
-                    color = div3(col, ct);
-                } else {
-                    float theta = acosf(clampf(dot3(d, nn), -1.f, 1.f));
-                    // leaving our own boundary: the medium outside is the enclosing volumetric object
-                    // (Scene.cpp:354-390); only homogeneous media count and none are resident yet
-                    int outside = (inside == hobj) ? -1 : hobj;
-                    float cur_n = inside >= 0 ? refr_coeff(sc.objects[inside]) : 1.f;
-                    float next_n = outside >= 0 ? refr_coeff(sc.objects[outside]) : 1.f;
-                    float sin_phi = cur_n / next_n * sinf(theta);
-                    if (sin_phi >= 1.f) {
-                        nd = refl;
-                        float ct = fabsf(dot3(nn, nd));
-                        ct = ct > 1e-6f ? ct : 1e-6f;
-                        color = div3(col, ct);
-                    } else {
-                        float phi = asinf(sin_phi);
-                        if ((double)theta > 3.14159265358979 / 2)
-                            phi = (float)(3.14159265358979 - (double)phi);
-                        f3 axis = normalize3(cross3(nn, d));
-                        f3 rdir = normalize3(rotate_about(axis, phi, nn));
-                        float cos_t = fabsf(cosf(theta)), cos_p = fabsf(cosf(phi));
-                        float a1 = fabsf(cur_n * cos_t - next_n * cos_p) / (cur_n * cos_t + next_n * cos_p);
-                        float a2 = fabsf(next_n * cos_t - cur_n * cos_p) / (next_n * cos_t + cur_n * cos_p);
-                        float er = (a1 * a1 + a2 * a2) / 2.f;
-                        float p = clampf(er, 0.f, 1.f);
-                        if (rng_float(key, ctr) < p) {
-                            nd = refl;
-                            float ct = fabsf(dot3(nn, nd));
-                            ct = ct > 1e-6f ? ct : 1e-6f;
-                            color = col * (er / ct);
-                            dirProb = p;
-                        } else {
-                            nd = rdir;
-                            float ct = fabsf(dot3(nn, nd));
-                            ct = ct > 1e-6f ? ct : 1e-6f;
-                            color = col * ((1.f - er) / ct);
-                            dirProb = 1.f - p;
-                            ninside = outside;
-                        }
-                    }
-                    nd = normalize3(nd);
-                }
-            }
-            if (!term && ob.type != MIRT_OBJ_EMISSIVE) {
-                thr = thr * div3(color, dirProb);
+            } else if (len3(nd) >= 0.5f) {
                 // Ray.cpp:71-78: cosine term of the new vertex against its contact normal
                 float ct = 1.f;
-                if (len3(nd) > 0.5f) ct = fabsf(dot3(nn, nd));
+                if (sr.cos_term) ct = fabsf(dot3(sr.nn, nd));
                 ct = ct > 1e-6f ? ct : 1e-6f;
                 thr = thr * ct;
                 // MCRenderer.cpp:181-191
-                alive = len3(nd) >= 0.5f && depth + 1 <= max_depth;
-                no = pos;
-                nids = MIRT_PACK_IDS(hobj, ninside);
+                alive = depth + 1 <= max_depth;
+                no = sr.pos;
+                nids = MIRT_PACK_IDS(sr.contact, sr.inside);
             }
         }
     }

@@ -157,6 +157,11 @@ public:
     std::vector<int32_t> triObj, triLocal;
     std::vector<float> triVn;        // 9 per triangle
     std::vector<MirtObject> objectDescs;
+    // Scene::objKDTrees (Scene.h / Scene.cpp:287-320): built for the volumetric objects, the only
+    // ones findInsideObject ever queries (Scene.cpp:369); empty trees elsewhere
+    std::vector<KDTree> objKDTrees;
+    std::vector<MirtObjTree> objTreeDescs;
+    void buildObjKDTrees();
     ~Scene();
     void setGPU(bool on) { useGPU = on; }
     bool usingGPU() const { return useGPU; }

@@ -100,6 +100,7 @@ int mirth_scene_from_arrays(int32_t n_verts, const float* verts, int32_t n_tris,
             if (!tri_vn) sc.objectDescs[o].has_vn = 0;
         }
         sc.tree.build();
+        sc.buildObjKDTrees();
     } catch (const std::exception& e) {
         g_err = e.what();
         delete s;

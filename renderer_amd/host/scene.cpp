@@ -75,6 +75,9 @@ void Scene::clear() {
     for (SceneObject* o : objects) delete o;
     objects.clear();
     tree.destroy();
+    for (KDTree& t : objKDTrees) t.destroy();
+    objKDTrees.clear();
+    objTreeDescs.clear();
     objTriangleOffsetMap.clear();
     triPos.clear();
     triObj.clear();
@@ -135,9 +138,55 @@ void Scene::buildKDTree(bool upload) {
         vi_offset += obj->getVertexNum();
     }
     tree.build();
+    buildObjKDTrees();
     if (useGPU && upload) {
         IntersectionHIP::init();
         IntersectionHIP::loadKDTreeToDevice(*this);
+    }
+}
+
+// Scene::buildObjKDTrees (Scene.cpp:287-320), restricted to the objects findInsideObject looks at.
+// Works from the concatenated lists (an object's triangles are contiguous there, with the same
+// vertex sharing as in the object's own lists), so scenes made from arrays get them too.
+void Scene::buildObjKDTrees() {
+    for (KDTree& t : objKDTrees) t.destroy();
+    objKDTrees.assign(objectDescs.size(), KDTree());
+    objTreeDescs.clear();
+    for (unsigned oi = 0; oi < objectDescs.size(); oi++) {
+        const MirtObject& m = objectDescs[oi];
+        if (m.type != MIRT_OBJ_VPM) continue;
+        KDTree& t = objKDTrees[oi];
+        std::vector<int> local(tree.vertexPositionList.size(), -1);
+        for (int i = 0; i < m.tri_count; i++) {
+            const KDTree::Triangle& g = tree.triangleList[(size_t)m.tri_begin + i];
+            KDTree::Triangle tri;
+            for (int k = 0; k < 3; k++) {
+                unsigned vi = g.vertexIndices[k];
+                if (local[vi] < 0) {
+                    local[vi] = (int)t.vertexPositionList.size();
+                    t.vertexPositionList.push_back(tree.vertexPositionList[vi]);
+                }
+                tri.vertexIndices[k] = (unsigned)local[vi];
+            }
+            tri.sourceInformation.objID = oi;
+            tri.sourceInformation.triangleID = (unsigned)i;
+            t.triangleList.push_back(tri);
+        }
+        t.build();
+    }
+    for (unsigned oi = 0; oi < objKDTrees.size(); oi++) {
+        const KDTree& t = objKDTrees[oi];
+        if (!t.built()) continue;
+        MirtObjTree d;
+        d.object = (int32_t)oi;
+        d.n_nodes = t.numNodes();
+        d.node_min = t.nodeMin.data();
+        d.node_max = t.nodeMax.data();
+        d.node_right = t.nodeRight.data();
+        d.node_leaf_begin = t.nodeLeafBegin.data();
+        d.node_leaf_end = t.nodeLeafEnd.data();
+        d.slot_tid = t.slotTid.data();
+        objTreeDescs.push_back(d);
     }
 }
 
@@ -159,6 +208,8 @@ MirtSceneDesc Scene::describe() const {
     d.tri_vn = triVn.data();
     d.n_objects = (int32_t)objectDescs.size();
     d.objects = objectDescs.data();
+    d.n_obj_trees = (int32_t)objTreeDescs.size();
+    d.obj_trees = objTreeDescs.data();
     return d;
 }
 

@@ -148,6 +148,47 @@ def fan_scene(n_fan=300, with_wall=True):
                                     np.concatenate(tri_obj), np.array(objects, ra.OBJECT_DTYPE), None)
 
 
+def _box(h, center=(0, 0, 0)):
+    """axis-aligned cube of half-size h: 12 triangles, outward face normals"""
+    cx, cy, cz = center
+    c = lambda x, y, z: (cx + h * x, cy + h * y, cz + h * z)
+    faces = [((-1, -1, -1), (-1, -1, 1), (-1, 1, 1), (-1, 1, -1), (-1, 0, 0)),
+             ((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1), (1, 0, 0)),
+             ((-1, -1, -1), (1, -1, -1), (1, -1, 1), (-1, -1, 1), (0, -1, 0)),
+             ((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1), (0, 1, 0)),
+             ((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (0, 0, -1)),
+             ((-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1), (0, 0, 1))]
+    vs, fs, off = [], [], 0
+    for p0, p1, p2, p3, n in faces:
+        v, f, _ = _quad(c(*p0), c(*p1), c(*p2), c(*p3), n)
+        vs.append(v)
+        fs.append(f + off)
+        off += 4
+    return np.concatenate(vs), np.concatenate(fs)
+
+
+def fog_box_scene(sigma_s, sigma_a, ior=1.0, g=0.0, light=50.0, extra=()):
+    """A homogeneous-medium cube [-1.5,1.5]^3 (object 0) holding an emissive quad at z = -1 that
+    faces +z (object 1) and optional extra parts [(verts, faces, object)], all flat-shaded."""
+    fog = _obj(ra.OBJ_VPM, has_vn=0, ior=ior)
+    fog["sigma_s"] = sigma_s
+    fog["sigma_a"] = sigma_a
+    fog["g"] = g
+    fog["volumetric"] = 1
+    bv, bf = _box(1.5)
+    lv, lf, _ = _quad((-0.3, -0.3, -1), (0.3, -0.3, -1), (0.3, 0.3, -1), (-0.3, 0.3, -1), (0, 0, 1))
+    parts = [(bv, bf, fog), (lv, lf, _obj(ra.OBJ_EMISSIVE, (light, light, light), has_vn=0))] + list(extra)
+    verts, tris, tri_obj, objects, off = [], [], [], [], 0
+    for oi, (pv, pf, ob) in enumerate(parts):
+        verts.append(pv)
+        tris.append(pf + off)
+        tri_obj.append(np.full(len(pf), oi, np.int32))
+        objects.append(ob)
+        off += len(pv)
+    return ra.HostScene.from_arrays(np.concatenate(verts).astype(np.float32), np.concatenate(tris).astype(np.uint32),
+                                    np.concatenate(tri_obj), np.array(objects, ra.OBJECT_DTYPE), None)
+
+
 def random_rays(n, seed, n_objects, inside_obj=-1):
     """half camera-like rays from (0,0,2), half interior rays; plus packed ids for mode 2"""
     rng = np.random.default_rng(seed)

@@ -153,6 +153,16 @@ class OracleScene:
         return verts[:min(n, cap)], rgb, n
 
 
+def _find_inside(self, o, d, current=-1):
+    a = [np.ascontiguousarray(x, np.float32) for x in (o, d)]
+    lib().orc_find_inside.restype = C.c_int32
+    lib().orc_find_inside.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    return int(lib().orc_find_inside(self.h, _p(a[0]), _p(a[1]), current))
+
+
+OracleScene.find_inside = _find_inside
+
+
 def box_intersect(bmin, bmax, o, d):
     a = [np.ascontiguousarray(x, np.float32) for x in (bmin, bmax, o, d)]
     return float(lib().orc_box_intersect(*[_p(x) for x in a]))

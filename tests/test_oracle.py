@@ -256,3 +256,47 @@ def test_furnace_energy(orc, ra):
     assert np.allclose(centre, 50, rtol=2e-3)
     assert img.max() <= 50 * 1.01  # pixel jitter moves |front.dir| against the centre value
     S.close()
+
+
+def test_find_inside_object(orc, ra):
+    """Scene::findInsideObject (Scene.cpp:354-390): inside the medium's cube in any direction, not
+    outside it, not when the medium is the object to skip."""
+    s = meshgen.fog_box_scene((0.3, 0.3, 0.3), (0.2, 0.2, 0.2))
+    S = orc.OracleScene(s.raw())
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        assert S.find_inside(rng.uniform(-1.4, 1.4, 3), d) == 0
+        assert S.find_inside(rng.uniform(-1.4, 1.4, 3), d, current=0) == -1
+        o = rng.uniform(1.6, 3, 3) * rng.choice([-1, 1], 3)
+        assert S.find_inside(o, d) == -1
+    S.close()
+    s.close()
+
+
+def test_medium_known_answers(orc, ra):
+    """SceneVPMObject.cpp:4-233 against closed forms, camera inside the medium (IOR 1, so the boundary
+    does nothing), looking straight at an emitter 2 units away:
+      * purely absorbing grey medium: every path either reaches the emitter with weight
+        T(d)/P_surface(d) = 1 or dies at a medium event, so the pixel estimates L * exp(-sigma_a d);
+      * no medium coefficients at all reduces to the vacuum answer L (sampDist = inf)."""
+    cam = ra.make_camera(32, 32, 400, position=(0, 0, 1), focus=(0, 0, -1))
+    for sa, expect in ((0.5, 50 * np.exp(-0.5 * 2.0)), (1e-6, 50.0)):
+        s = meshgen.fog_box_scene((0, 0, 0), (sa, sa, sa))
+        S = orc.OracleScene(s.raw())
+        spp = 256
+        img, _ = S.render(cam, spp, seed=2, threads=8)
+        got = (img / spp)[8:24, 8:24].mean()
+        assert abs(got - expect) / expect < 0.02, (sa, got, expect)
+        S.close()
+        s.close()
+    # a scattering medium: single scattering adds light, absorption removes it; the directly seen
+    # emitter is attenuated by exp(-sigma_t d) and in-scattering can only add to that
+    s = meshgen.fog_box_scene((0.4, 0.4, 0.4), (0.1, 0.1, 0.1))
+    S = orc.OracleScene(s.raw())
+    img, _ = S.render(cam, 256, seed=2, threads=8)
+    got = (img / 256)[8:24, 8:24].mean()
+    assert 50 * np.exp(-0.5 * 2.0) * 0.97 < got < 50.0, got
+    S.close()
+    s.close()
