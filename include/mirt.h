@@ -164,6 +164,19 @@ int mirt_intersect(MirtContext* ctx, const float* origins, const float* directio
 int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* directions,
                        const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
                        void* stream);
+/* --- batched visibility ---------------------------------------------------------------------
+ * replaces MCRenderer::testVisibility (MCRenderer.cpp:106-118) for a batch: visible[i] = 1 when the
+ * closest hit under `mode` (normally MIRT_MODE_NO_SELF, aux as above) does not exist or satisfies
+ * dist - max_dist[i] >= -EPSILON (1e-5, macros.h:5), else 0; max_dist[i] is the distance between the
+ * two vertices being connected. Evaluated as an any-hit query that stops at the first occluder and
+ * never enters boxes beyond the limit; the answer is the reference's, not an approximation of it.
+ * (The GL variant Scene::testVisibility, Scene.cpp:455-508, is two mirt_intersect calls in mode 1
+ * plus its retest rule: see Scene::testVisibility in renderer_amd/host/scene.cpp.)
+ * Host pointers / device pointers + stream, like mirt_intersect / mirt_intersect_dev.            */
+int mirt_visibility(MirtContext* ctx, const float* origins, const float* directions, const int32_t* aux,
+                    const float* max_dist, size_t n, int mode, uint8_t* visible);
+int mirt_visibility_dev(MirtContext* ctx, const float* origins, const float* directions, const int32_t* aux,
+                        const float* max_dist, size_t n, int mode, uint8_t* visible, void* stream);
 /* Instrumented run (never timed): same results plus the number of node-box tests and
  * triangle tests summed over the batch (SURVEY.md §8(d) algorithmic-bytes formula). Device ptrs. */
 int mirt_intersect_count_dev(MirtContext* ctx, const float* origins, const float* directions,

@@ -50,6 +50,10 @@ int mirth_render(MirthScene* s, uint32_t spp, uint32_t seed, float* rgb_mean, Mi
  * object ids (-1 = NULL) -> dist[n], global tid[n] (-1 = miss), objID[n], local triangle id[n] */
 int mirth_fill_intersect(MirthScene* s, size_t n, const float* o, const float* d, const int32_t* contact,
                          const int32_t* inside, float* dist, int32_t* tid, int32_t* obj, int32_t* local);
+/* Scene::testVisibility (Scene.cpp:455-508) on AoS rays: dist[n] = distance to the vertex being
+ * connected (Ray::intersectDist there) -> visible[n] (1 = unoccluded, MCRenderer.cpp:115-117 rule) */
+int mirth_test_visibility(MirthScene* s, size_t n, const float* o, const float* d, const int32_t* contact,
+                          const int32_t* inside, const float* dist, uint8_t* visible);
 void mirth_shutdown(void);
 
 int mirth_save_pfm(const char* path, const float* rgb, int32_t w, int32_t h);

@@ -1182,6 +1182,21 @@ void orc_intersect(const OrcScene* s, const float* origins, const float* directi
     }
 }
 
+void orc_visibility(const OrcScene* s, const float* origins, const float* directions,
+                    const int32_t* aux, const float* max_dist, size_t n, int mode,
+                    uint8_t* visible, int threads) {
+    (void)threads;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads > 0 ? threads : 1)
+    for (long long i = 0; i < (long long)n; i++) {
+        KRay r = loadRay(origins, directions, n, (size_t)i);
+        Condition c = makeCond(mode, aux ? aux[i] : 0);
+        unsigned tid = 0;
+        float dist = s->root ? nodeIntersect(*s, r, s->root, tid, mode ? &c : nullptr, nullptr) : -1;
+        // MCRenderer.cpp:117: srInfo.dist<0 || (srInfo.dist - length >= -EPSILON)
+        visible[i] = (dist < 0 || (dist - max_dist[i] >= -1e-5f)) ? 1 : 0;
+    }
+}
+
 void orc_intersect_ref_counts(const OrcScene* s, const float* origins, const float* directions,
                               const int32_t* aux, size_t n, int mode, uint64_t* n_box,
                               uint64_t* n_tri) {

@@ -65,6 +65,11 @@ void orc_tree_flatten(const OrcScene* s, float* node_min, float* node_max, int32
 void orc_intersect(const OrcScene* s, const float* origins, const float* directions,
                    const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
                    int threads);
+/* MCRenderer::testVisibility (MCRenderer.cpp:106-118) per ray: 1 when the reference closest hit
+ * under `mode` is a miss or dist - max_dist[i] >= -EPSILON (macros.h:5), else 0.                  */
+void orc_visibility(const OrcScene* s, const float* origins, const float* directions,
+                    const int32_t* aux, const float* max_dist, size_t n, int mode,
+                    uint8_t* visible, int threads);
 /* per-ray visit counters of the REFERENCE traversal order (both children, no pruning) */
 void orc_intersect_ref_counts(const OrcScene* s, const float* origins, const float* directions,
                               const int32_t* aux, size_t n, int mode, uint64_t* n_box,

@@ -52,11 +52,11 @@ class SceneDesc(C.Structure):
 
 # every symbol include/mirt.h and include/mirt_host.h declare (checked by the CPU tests)
 MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_scene", "mirt_intersect",
-                "mirt_intersect_dev", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
+                "mirt_intersect_dev", "mirt_visibility", "mirt_visibility_dev", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
                 "mirt_render_pt_dev", "mirt_capture_rays_dev", "mirt_device_info"]
 MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
-                 "mirth_describe", "mirth_upload", "mirth_render", "mirth_fill_intersect", "mirth_shutdown",
+                 "mirth_describe", "mirth_upload", "mirth_render", "mirth_fill_intersect", "mirth_test_visibility", "mirth_shutdown",
                  "mirth_save_pfm", "mirth_load_pfm"]
 
 _lib = None
@@ -92,6 +92,9 @@ def lib():
         L.mirt_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                      C.c_void_p, C.c_void_p]
         L.mirt_intersect_dev.argtypes = L.mirt_intersect.argtypes + [C.c_void_p]
+        L.mirt_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_int, C.c_void_p]
+        L.mirt_visibility_dev.argtypes = L.mirt_visibility.argtypes + [C.c_void_p]
         L.mirt_intersect_count_dev.argtypes = L.mirt_intersect.argtypes + [C.POINTER(C.c_uint64),
                                                                           C.POINTER(C.c_uint64)]
         L.mirt_intersect_audit_dev.argtypes = L.mirt_intersect.argtypes + [C.POINTER(C.c_uint64 * 8)]
@@ -115,6 +118,7 @@ def lib():
         L.mirth_upload.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.mirth_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(RenderStats)]
         L.mirth_fill_intersect.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 8
+        L.mirth_test_visibility.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
         L.mirth_save_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         L.mirth_load_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32 * 2)]
         _lib = L
@@ -227,6 +231,20 @@ class HostScene:
             raise MirtError(lib().mirth_last_error().decode())
         return dist, tid, obj, local
 
+    def test_visibility(self, o, d, contact, inside, dist):
+        """Scene::testVisibility on AoS rays [n,3]; dist[n] = distance to the connected vertex."""
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        n = len(o)
+        contact = np.ascontiguousarray(contact, np.int32)
+        inside = np.ascontiguousarray(inside, np.int32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        vis = np.empty(n, np.uint8)
+        if lib().mirth_test_visibility(self.h, n, _ptr(o), _ptr(d), _ptr(contact), _ptr(inside), _ptr(dist),
+                                       _ptr(vis)) != 0:
+            raise MirtError(lib().mirth_last_error().decode())
+        return vis
+
 
 def pack_ids(contact, inside):
     contact = np.asarray(contact, np.int64)
@@ -274,6 +292,22 @@ class Device:
         tid = np.empty(n, np.int32)
         self._check(lib().mirt_intersect(self.ctx, _ptr(o), _ptr(d), _ptr(a), n, mode, _ptr(t), _ptr(tid)))
         return t, tid
+
+    def visibility(self, origins, directions, aux, max_dist, mode=MODE_NO_SELF):
+        """MCRenderer::testVisibility for a batch (host arrays): uint8[n], 1 = nothing nearer than max_dist."""
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(directions, np.float32)
+        assert o.ndim == 2 and o.shape[0] == 3 and o.shape == d.shape
+        n = o.shape[1]
+        a = None if aux is None else np.ascontiguousarray(aux, np.int32)
+        m = np.ascontiguousarray(max_dist, np.float32)
+        assert m.shape == (n,)
+        vis = np.empty(n, np.uint8)
+        self._check(lib().mirt_visibility(self.ctx, _ptr(o), _ptr(d), _ptr(a), _ptr(m), n, mode, _ptr(vis)))
+        return vis
+
+    def visibility_dev(self, o_ptr, d_ptr, aux_ptr, max_dist_ptr, n, mode, vis_ptr, stream=None):
+        self._check(lib().mirt_visibility_dev(self.ctx, o_ptr, d_ptr, aux_ptr, max_dist_ptr, n, mode, vis_ptr, stream))
 
     def intersect_dev(self, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr, stream=None):
         self._check(lib().mirt_intersect_dev(self.ctx, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr, stream))

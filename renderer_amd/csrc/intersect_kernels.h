@@ -66,13 +66,18 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
 // MODE: MIRT_MODE_*   COUNT: audit counters (never timed)   SLOT_OUT: write the slot index (internal
 // path-tracing use) instead of the global triangle id.
 // `queue`: one zero-initialised word per launch, the index of the next unassigned ray.
-template <int MODE, bool COUNT, bool SLOT_OUT>
+// ANYHIT: visibility query (MCRenderer::testVisibility, MCRenderer.cpp:106-118): instead of the
+// closest hit, vis_out[i] = 1 unless some legal hit has t - limit[i] < -EPSILON (macros.h:5), which
+// is exactly "closest legal hit is nearer than the limit" because the rounded difference is
+// monotone in t. The traversal stops at the first such hit and never enters boxes beyond the limit.
+template <int MODE, bool COUNT, bool SLOT_OUT, bool ANYHIT = false>
 __global__ void __launch_bounds__(256)
 k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ D,
             const int* __restrict__ aux, uint32_t n_direct, const uint32_t* __restrict__ n_ptr,
             uint32_t plane_stride, float* __restrict__ t_out,
             int* __restrict__ id_out, unsigned long long* __restrict__ counters,
-            uint32_t* __restrict__ queue, uint32_t lds_levels, uint2* __restrict__ spill) {
+            uint32_t* __restrict__ queue, uint32_t lds_levels, uint2* __restrict__ spill,
+            const float* __restrict__ limit = nullptr, unsigned char* __restrict__ vis_out = nullptr) {
     extern __shared__ uint32_t lds[];
     // ray count: given, or (wavefront path tracer) left in device memory by the previous shade pass
     const uint32_t n = n_ptr ? min(*n_ptr, n_direct) : n_direct;
@@ -99,6 +104,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     float best = -1.f, thr = INF;  // thr: entry distances beyond it cannot beat the closest hit (prune())
     int best_slot = -1, sp = 0, link = 0;
     int leaf_pos = 0, leaf_end = 0;  // triangles still to test in the current leaf
+    float lim = 0.f;                 // ANYHIT: distance limit of this ray
+    bool occluded = false;
     RayPre pre;
     pre.inv = mk3(0, 0, 0);
     pre.a_ray = 0.f;
@@ -139,6 +146,11 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         }
     };
     auto accept = [&](float t, int s) {  // a legal candidate that beats the closest hit so far
+        if (ANYHIT) {  // (only candidates nearer than the limit get here) one occluder is enough
+            occluded = true;
+            has = false;
+            return;
+        }
         best = t;
         best_slot = s;
         thr = t * 1.0001f + 1e-5f;
@@ -170,6 +182,11 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 if (MODE != MIRT_MODE_UNCONDITIONAL) a = aux[idx];
                 best = -1.f;
                 thr = INF;
+                if (ANYHIT) {
+                    lim = limit[idx];
+                    thr = lim * 1.0001f + 1e-5f;  // nothing beyond the limit can occlude
+                    occluded = false;
+                }
                 best_slot = -1;
                 sp = 0;
                 has = false;
@@ -248,6 +265,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                         if (COUNT) au.tri++;
                         const float t = tri_test(T, o, d);
                         if (!(t >= 0.f)) continue;
+                        if (ANYHIT && t - lim >= -1e-5f) continue;  // at or beyond the limit: no occluder
                         if (!(best_slot < 0 || t < best || (t == best && best_slot < leaf_beg))) continue;
                         if (MODE == MIRT_MODE_NO_SELF) {
                             cand = s;
@@ -257,6 +275,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                         }
                         if (MODE == MIRT_MODE_LAST_TID && __float_as_int(sc.vns[s].n1.w) == a) continue;
                         accept(t, s);
+                        if (ANYHIT && !has) break;
                     }
                     leaf_pos = s;
                 }
@@ -275,7 +294,12 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         if (active && has && leaf_pos >= leaf_end) pop();
 
         // ---- retire finished rays -----------------------------------------------------------------
-        if (active && !has) {
+        if (ANYHIT) {
+            if (active && !has) {
+                vis_out[idx] = occluded ? 0 : 1;
+                active = false;
+            }
+        } else if (active && !has) {
             t_out[idx] = best_slot >= 0 ? best : -1.f;
             if (SLOT_OUT)
                 id_out[idx] = best_slot;

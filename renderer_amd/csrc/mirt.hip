@@ -608,6 +608,29 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
     return MIRT_OK;
 }
 
+// visibility variant: vis_out[i] = 1 unless a legal hit lies nearer than limit[i]
+static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
+                             const int* aux, const float* limit, uint32_t n, uint32_t stride,
+                             unsigned char* vis_out) {
+    if (n == 0) return MIRT_OK;
+    const uint32_t want = (n + ctx->block - 1) / ctx->block;
+    dim3 block(ctx->block), grid(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), st));
+#define MIRT_VIS(MODE)                                                                                        \
+    hipLaunchKernelGGL((k_intersect<MODE, false, false, true>), grid, block, ctx->lds_main, st, ctx->sc, O, D, aux, \
+                       n, (const uint32_t*)nullptr, stride, (float*)nullptr, (int*)nullptr, ctx->d_counters,     \
+                       ctx->d_queue, ctx->lds_levels, ctx->d_spill, limit, vis_out)
+    switch (mode) {
+        case MIRT_MODE_UNCONDITIONAL: MIRT_VIS(MIRT_MODE_UNCONDITIONAL); break;
+        case MIRT_MODE_LAST_TID: MIRT_VIS(MIRT_MODE_LAST_TID); break;
+        case MIRT_MODE_NO_SELF: MIRT_VIS(MIRT_MODE_NO_SELF); break;
+        default: return fail(ctx, MIRT_E_INVALID, "visibility: unknown mode");
+    }
+#undef MIRT_VIS
+    HIPCHK(ctx, hipGetLastError());
+    return MIRT_OK;
+}
+
 static int check_intersect_args(MirtContext* ctx, const float* o, const float* d, const int32_t* aux,
                                 size_t n, int mode, float* t_out, int32_t* tid_out) {
     if (!ctx) return MIRT_E_INVALID;
@@ -696,6 +719,59 @@ int mirt_intersect(MirtContext* ctx, const float* origins, const float* directio
         if (rc != MIRT_OK) return rc;
         HIPCHK(ctx, hipMemcpyAsync(t_out + b, ctx->st_t, m * sizeof(float), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipMemcpyAsync(tid_out + b, ctx->st_id, m * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    return MIRT_OK;
+}
+
+int mirt_visibility_dev(MirtContext* ctx, const float* origins, const float* directions, const int32_t* aux,
+                        const float* max_dist, size_t n, int mode, uint8_t* visible, void* stream) {
+    float dummy_t;
+    int32_t dummy_i;
+    int rc = check_intersect_args(ctx, origins, directions, aux, n, mode, &dummy_t, &dummy_i);
+    if (rc != MIRT_OK) return rc;
+    if (n && (!max_dist || !visible)) return fail(ctx, MIRT_E_INVALID, "visibility: NULL max_dist / visible");
+    if (n == 0) return MIRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    return launch_visibility(ctx, st, mode, origins, directions, aux, max_dist, (uint32_t)n, (uint32_t)n, visible);
+}
+
+int mirt_visibility(MirtContext* ctx, const float* origins, const float* directions, const int32_t* aux,
+                    const float* max_dist, size_t n, int mode, uint8_t* visible) {
+    float dummy_t;
+    int32_t dummy_i;
+    int rc = check_intersect_args(ctx, origins, directions, aux, n, mode, &dummy_t, &dummy_i);
+    if (rc != MIRT_OK) return rc;
+    if (n && (!max_dist || !visible)) return fail(ctx, MIRT_E_INVALID, "visibility: NULL max_dist / visible");
+    if (n == 0) return MIRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t CH = 1u << 24;  // rays per staged chunk
+    size_t cap = std::min(n, CH);
+    if (cap > ctx->st_cap) {
+        free_staging(ctx);
+        HIPCHK(ctx, hipMalloc(&ctx->st_o, 3 * cap * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&ctx->st_d, 3 * cap * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&ctx->st_aux, cap * sizeof(int)));
+        HIPCHK(ctx, hipMalloc(&ctx->st_t, cap * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&ctx->st_id, cap * sizeof(int)));
+        ctx->st_cap = cap;
+    }
+    hipStream_t st = ctx->stream;
+    for (size_t b = 0; b < n; b += CH) {
+        size_t m = std::min(CH, n - b);
+        for (int c = 0; c < 3; c++) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->st_o + c * m, origins + c * n + b, m * sizeof(float), hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->st_d + c * m, directions + c * n + b, m * sizeof(float), hipMemcpyHostToDevice, st));
+        }
+        if (mode != MIRT_MODE_UNCONDITIONAL)
+            HIPCHK(ctx, hipMemcpyAsync(ctx->st_aux, aux + b, m * sizeof(int), hipMemcpyHostToDevice, st));
+        // limits travel in the t staging buffer, flags come back in the id staging buffer
+        HIPCHK(ctx, hipMemcpyAsync(ctx->st_t, max_dist + b, m * sizeof(float), hipMemcpyHostToDevice, st));
+        rc = launch_visibility(ctx, st, mode, ctx->st_o, ctx->st_d, ctx->st_aux, ctx->st_t, (uint32_t)m, (uint32_t)m,
+                               (unsigned char*)ctx->st_id);
+        if (rc != MIRT_OK) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(visible + b, ctx->st_id, m, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
     }
     return MIRT_OK;

@@ -224,6 +224,14 @@ std::vector<vec3f> MCRenderer::renderPixels(const Camera& camera) {
     return std::vector<vec3f>((size_t)camera.width * camera.height, vec3f(0, 0, 0));  // MCRenderer.h:114-117
 }
 
+// MCRenderer::testVisibility (MCRenderer.cpp:106-118): shoot startRay with its own
+// NoSelfIntersectionCondition; visible when nothing legal lies nearer than the end vertex.
+bool MCRenderer::testVisibility(const Ray& startRay, const Ray& endRay) {
+    std::vector<Ray> one(1, startRay);
+    one[0].intersectDist = (startRay.origin - endRay.origin).length();
+    return renderer->scene.testVisibility(one)[0];
+}
+
 // MCRenderer.cpp:500-518: "PF\nW H\n-1.000000\n", rows bottom-to-top, channels R,G,B, little-endian
 void MCRenderer::saveImagePFM(const std::string& fileName, const std::vector<vec3f>& pixels, int w, int h) {
     FILE* f = fopen(fileName.c_str(), "wb");

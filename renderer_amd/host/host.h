@@ -170,6 +170,9 @@ public:
     MirtSceneDesc describe() const;  // pointers stay valid until the scene changes
     float intersect(const Ray& ray, ObjSourceInformation& objSource);  // unconditional, 1-ray batch
     void fillIntersectObject(std::vector<Ray>& rays);                  // Scene.cpp:431-453
+    // Scene::testVisibility (Scene.cpp:455-508): rays[i].intersectDist holds the distance to the
+    // vertex being connected; true = nothing legal nearer than it (MCRenderer.cpp:115-117 rule)
+    std::vector<bool> testVisibility(const std::vector<Ray>& rays);
     int getContactTreeTid(const Ray& ray) const;                       // Scene.cpp:420-429
     vec3f getDiagonal() const { return tree.getDiagonal(); }
 };
@@ -192,6 +195,8 @@ public:
     void setSavePath(const std::string& p) { savePath = p; }
     const std::string& getSavePath() const { return savePath; }
     virtual std::vector<vec3f> renderPixels(const Camera& camera);
+    // MCRenderer::testVisibility (MCRenderer.cpp:106-118), a one-ray batch on the device
+    bool testVisibility(const Ray& startRay, const Ray& endRay);
     // PFM writer with the reference's layout (MCRenderer.cpp:500-518)
     static void saveImagePFM(const std::string& fileName, const std::vector<vec3f>& pixels, int w, int h);
     static bool loadImagePFM(const std::string& fileName, std::vector<vec3f>& pixels, int& w, int& h);

@@ -232,6 +232,28 @@ int mirth_fill_intersect(MirthScene* s, size_t n, const float* o, const float* d
     })
 }
 
+int mirth_test_visibility(MirthScene* s, size_t n, const float* o, const float* d, const int32_t* contact,
+                          const int32_t* inside, const float* dist, uint8_t* visible) {
+    if (!s || !o || !d || !dist || !visible) return -1;
+    GUARD({
+        Scene& sc = s->renderer.scene;
+        if (sc.objects.empty()) throw std::runtime_error("mirth_test_visibility: needs a scene loaded from a config");
+        std::vector<Ray> rays(n);
+        for (size_t i = 0; i < n; i++) {
+            rays[i].origin = vec3f(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+            rays[i].direction = vec3f(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+            int c = contact ? contact[i] : -1, in = inside ? inside[i] : -1;
+            if (c >= (int)sc.objects.size() || in >= (int)sc.objects.size())
+                throw std::runtime_error("mirth_test_visibility: object id out of range");
+            rays[i].contactObject = c >= 0 ? sc.objects[c] : nullptr;
+            rays[i].insideObject = in >= 0 ? sc.objects[in] : nullptr;
+            rays[i].intersectDist = dist[i];
+        }
+        std::vector<bool> v = sc.testVisibility(rays);
+        for (size_t i = 0; i < n; i++) visible[i] = v[i] ? 1 : 0;
+    })
+}
+
 void mirth_shutdown(void) { IntersectionHIP::shutdown(); }
 
 int mirth_save_pfm(const char* path, const float* rgb, int32_t w, int32_t h) {

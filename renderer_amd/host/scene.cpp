@@ -255,4 +255,34 @@ void Scene::fillIntersectObject(std::vector<Ray>& rays) {
     }
 }
 
+// Scene::testVisibility (Scene.cpp:455-508). The reference's GL route skips only the start triangle
+// (last_tid) and then re-shoots rays whose first hit was an illegal self / inside hit; that retest
+// is its approximation of NoSelfIntersectionCondition. Here the query runs the predicate itself
+// (as fillIntersectObject does), i.e. the rule of the CPU route MCRenderer::testVisibility
+// (MCRenderer.cpp:115-117), as one any-hit batch: no second pass is needed.
+std::vector<bool> Scene::testVisibility(const std::vector<Ray>& rays) {
+    MirtContext* ctx = IntersectionHIP::context();
+    if (!ctx) throw std::runtime_error("Scene::testVisibility: IntersectionHIP::init() was not called");
+    const size_t n = rays.size();
+    std::vector<bool> visibilityList(n);
+    if (n == 0) return visibilityList;
+    std::vector<float> o(3 * n), d(3 * n), lim(n);
+    std::vector<int32_t> aux(n);
+    std::vector<uint8_t> vis(n);
+    for (size_t i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) {
+            o[c * n + i] = rays[i].origin[c];
+            d[c * n + i] = rays[i].direction[c];
+        }
+        int contact = rays[i].contactObject ? rays[i].contactObject->objectIndex : -1;
+        int inside = rays[i].insideObject ? rays[i].insideObject->objectIndex : -1;
+        aux[i] = MIRT_PACK_IDS(contact, inside);
+        lim[i] = rays[i].intersectDist;
+    }
+    if (mirt_visibility(ctx, o.data(), d.data(), aux.data(), lim.data(), n, MIRT_MODE_NO_SELF, vis.data()) != MIRT_OK)
+        throw std::runtime_error(std::string("Scene::testVisibility: ") + mirt_last_error(ctx));
+    for (size_t i = 0; i < n; i++) visibilityList[i] = vis[i] != 0;
+    return visibilityList;
+}
+
 }  // namespace mirt_host

@@ -107,6 +107,17 @@ class OracleScene:
         lib().orc_intersect(self.h, _p(o), _p(d), _p(a), n, mode, _p(t), _p(tid), threads)
         return t, tid
 
+    def visibility(self, o, d, aux, max_dist, mode=2, threads=8):
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        a = None if aux is None else np.ascontiguousarray(aux, np.int32)
+        m = np.ascontiguousarray(max_dist, np.float32)
+        vis = np.empty(o.shape[1], np.uint8)
+        lib().orc_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_int, C.c_void_p, C.c_int]
+        lib().orc_visibility(self.h, _p(o), _p(d), _p(a), _p(m), o.shape[1], mode, _p(vis), threads)
+        return vis
+
     def ref_counts(self, o, d, aux=None, mode=0):
         o = np.ascontiguousarray(o, np.float32)
         d = np.ascontiguousarray(d, np.float32)

@@ -173,6 +173,26 @@ def test_ordered_traversal_matches_reference_order(cornell_oracle, mesh20k_oracl
             assert nb / 20000 < rb / 2000  # pruning visits fewer boxes than the reference order
 
 
+def test_visibility_known_answers(cornell_oracle):
+    """MCRenderer::testVisibility (MCRenderer.cpp:115-117): visible iff no legal hit, or the closest
+    one is not nearer than the connected vertex by more than EPSILON. Worked from the Cornell
+    geometry: floor y=-1, ceiling y=+1, camera-side open."""
+    S = cornell_oracle
+    o = np.array([[0.9, 0.0, 0.9]] * 6, np.float32).T.copy()
+    d = np.array([[0, -1, 0]] * 5 + [[0, 0, 1]], np.float32).T.copy()
+    # the floor lies at distance 1 below (0.9, 0, 0.9)
+    lim = np.array([0.5, 1.0, 1.00002, 1.000009, 2.0, 5.0], np.float32)
+    vis = S.visibility(o, d, None, lim, 0, threads=1)
+    assert vis.tolist() == [1, 1, 0, 1, 0, 1]  # last ray leaves through the open front: always visible
+    # consistency with the closest hit on random rays, every mode
+    o, d, aux = meshgen.random_rays(20000, 17, 8, inside_obj=2)
+    for mode, a in ((0, None), (2, aux)):
+        t, _ = S.intersect(o, d, a, mode, threads=8)
+        lim = (np.where(t >= 0, t, 1) * np.random.default_rng(mode).choice([0.5, 1.0, 1.5], len(t))).astype(np.float32)
+        vis = S.visibility(o, d, a, lim, mode, threads=8)
+        assert np.array_equal(vis, ((t < 0) | (t - lim >= np.float32(-1e-5))).astype(np.uint8))
+
+
 def test_predicate_cases(cornell_oracle):
     """NoSelfIntersectionCondition.cpp:12-27 on the floor (object 6, normal +y)."""
     S = cornell_oracle
