@@ -54,6 +54,10 @@ int mirth_fill_intersect(MirthScene* s, size_t n, const float* o, const float* d
  * connected (Ray::intersectDist there) -> visible[n] (1 = unoccluded, MCRenderer.cpp:115-117 rule) */
 int mirth_test_visibility(MirthScene* s, size_t n, const float* o, const float* d, const int32_t* contact,
                           const int32_t* inside, const float* dist, uint8_t* visible);
+/* Host math used while flattening a scene: transform * (v,1) (SimpleShape.h:46) and
+ * transpose(inverse(transform)) * (vn,0) (SimpleShape.cpp:310,322); m[r*4+c] = element(r,c). */
+void mirth_world_vertex(const float m[16], const float v[3], float out[3]);
+void mirth_normal_transform(const float m[16], const float vn[3], float out[3]);
 void mirth_shutdown(void);
 
 int mirth_save_pfm(const char* path, const float* rgb, int32_t w, int32_t h);

@@ -222,16 +222,16 @@ float boxIntersect(const V3& minC, const V3& maxC, const KRay& ray) {
 
 // SimpleShape.cpp:300-339 (world positions already transformed; vns already multiplied by the
 // normal matrix on the host, SimpleShape.cpp:310,322)
-V3 worldNormal(const OrcScene& S, unsigned tid, const V3& position) {
-    V3 vps[3];
-    for (int i = 0; i < 3; i++) vps[i] = S.verts[S.tris[tid].v[i]];
+V3 faceNormalOf(const V3 vps[3]) {
     V3 b1 = vps[1] - vps[0];
     V3 b2 = vps[2] - vps[0];
     V3 faceNormal = cross(b1, b2);
     normalize(faceNormal);
-    const OrcObject& obj = S.objects[S.triObj[tid]];
-    if (!obj.has_vn || S.triVn.empty()) return faceNormal;
-    const V3* vns = &S.triVn[3 * (size_t)tid];
+    return faceNormal;
+}
+V3 interpNormal(const V3 vps[3], const V3 vns[3], const V3& position) {  // SimpleShape.cpp:329-337
+    V3 b1 = vps[1] - vps[0];
+    V3 b2 = vps[2] - vps[0];
     V3 v = position - vps[0];
     float d12 = dot(b1, b2);
     float l1 = length(b1);
@@ -241,6 +241,13 @@ V3 worldNormal(const OrcScene& S, unsigned tid, const V3& position) {
     V3 normal = (1 - u1 - u2) * vns[0] + u1 * vns[1] + u2 * vns[2];
     normalize(normal);
     return normal;
+}
+V3 worldNormal(const OrcScene& S, unsigned tid, const V3& position) {
+    V3 vps[3];
+    for (int i = 0; i < 3; i++) vps[i] = S.verts[S.tris[tid].v[i]];
+    const OrcObject& obj = S.objects[S.triObj[tid]];
+    if (!obj.has_vn || S.triVn.empty()) return faceNormalOf(vps);
+    return interpNormal(vps, &S.triVn[3 * (size_t)tid], position);
 }
 
 // NoSelfIntersectionCondition.cpp:12-27
@@ -1291,6 +1298,45 @@ void orc_camera_ray(const OrcCamera* cam, uint32_t pixel, float u, float v, floa
     dir_out[1] = dir.y;
     dir_out[2] = dir.z;
 }
+
+static void put(const V3& v, float out[3]) { out[0] = v.x, out[1] = v.y, out[2] = v.z; }
+static V3 get(const float v[3]) { return V3(v[0], v[1], v[2]); }
+
+void orc_local_frame(const float n[3], float s_out[3], float t_out[3]) {
+    LocalFrame lf;
+    lf.buildFromNormal(get(n));
+    put(lf.s, s_out);
+    put(lf.t, t_out);
+}
+void orc_to_world(const float n[3], const float a[3], float out[3]) {
+    LocalFrame lf;
+    lf.buildFromNormal(get(n));
+    put(lf.toWorld(get(a)), out);
+}
+float orc_hg_eval(float g, const float in[3], const float outd[3]) {
+    return Tracer::hgValue(g, dot(get(in), get(outd)));
+}
+void orc_face_normal(const float p0[3], const float p1[3], const float p2[3], float out[3]) {
+    V3 vps[3] = {get(p0), get(p1), get(p2)};
+    put(faceNormalOf(vps), out);
+}
+void orc_interp_normal(const float p0[3], const float p1[3], const float p2[3], const float n0[3],
+                       const float n1[3], const float n2[3], const float position[3], float out[3]) {
+    V3 vps[3] = {get(p0), get(p1), get(p2)};
+    V3 vns[3] = {get(n0), get(n1), get(n2)};
+    put(interpNormal(vps, vns, get(position)), out);
+}
+void orc_rotate(const float axis[3], float angle, const float v[3], float out[3]) {
+    put(Tracer::rotate(get(axis), angle, get(v)), out);
+}
+void orc_normalize(const float v[3], float out[3]) {
+    V3 r = get(v);
+    normalize(r);
+    put(r, out);
+}
+void orc_div(const float v[3], float d, float out[3]) { put(get(v) / d, out); }
+float orc_dot(const float a[3], const float b[3]) { return dot(get(a), get(b)); }
+float orc_length(const float a[3]) { return length(get(a)); }
 
 void orc_hemi_cos(float expTerm, float u1, float u2, float out[3]) {
     V3 r = Tracer::hemiCos(expTerm, u1, u2);

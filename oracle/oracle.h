@@ -7,11 +7,16 @@
  * both-children traversal, recursive samplePath with a stored vertex list) so that it can be read
  * side by side with the reference files each function cites.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or images for this path
- * (SURVEY.md §4), and its sources cannot be compiled in this image without writing stand-in
- * headers (every .cpp includes the MSVC precompiled header "StdAfx.h" -> <tchar.h>,
- * <SDKDDKVer.h>; the integrator base needs OpenCV and <io.h>), so there is no oracle/_ref.
- * The restatement is checked only against hand-derived known answers and its own invariants.
+ * PARITY UNPINNED for the traversal, the predicate, the materials and the sample loop: the
+ * reference ships no tests, golden vectors or images for this path, and its .cpp
+ * files cannot be compiled in this image without writing stand-in headers (every one includes the
+ * MSVC precompiled header "StdAfx.h" -> <tchar.h>, <SDKDDKVer.h>; the integrator base needs OpenCV
+ * and <io.h>). Those parts are checked only against hand-derived known answers and invariants.
+ * PINNED: the math layer under them. The reference's header-only code (nvVector.h, nvMatrix.h,
+ * LocalFrame.h, HGPhaseFunc.h) does build here unmodified; oracle/ref_math.cpp drives it in place
+ * (oracle/_ref/libref_math.so) and tests/golden/ref_math.npz records its outputs, which the
+ * orc_* math entry points below and the product's host math reproduce bit for bit
+ * (tests/test_ref_math.py).
  */
 #ifndef ORACLE_H
 #define ORACLE_H
@@ -92,6 +97,20 @@ int orc_legal(const OrcScene* s, int32_t tid, const float o[3], const float d[3]
 uint32_t orc_rng_draw(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t dim);
 void orc_camera_ray(const OrcCamera* cam, uint32_t pixel, float u, float v, float dir_out[3]);
 void orc_hemi_cos(float expTerm, float u1, float u2, float out[3]); /* RandGenerator.cpp:152-168 */
+/* the math layer, one function each, pinned bit for bit against the reference's own headers
+ * compiled in place (oracle/ref_math.cpp -> tests/golden/ref_math.npz) */
+void orc_local_frame(const float n[3], float s_out[3], float t_out[3]); /* LocalFrame.h:14-23 */
+void orc_to_world(const float n[3], const float a[3], float out[3]);    /* LocalFrame.h:25-28 */
+float orc_hg_eval(float g, const float in[3], const float outd[3]);     /* HGPhaseFunc.h:11-17 */
+void orc_face_normal(const float p0[3], const float p1[3], const float p2[3], float out[3]);
+void orc_interp_normal(const float p0[3], const float p1[3], const float p2[3], const float n0[3],
+                       const float n1[3], const float n2[3], const float position[3],
+                       float out[3]); /* SimpleShape.cpp:311-314, 329-337 */
+void orc_rotate(const float axis[3], float angle, const float v[3], float out[3]); /* smallFuncs.h:11-24 */
+void orc_normalize(const float v[3], float out[3]); /* nvVector.h:522-526 */
+void orc_div(const float v[3], float d, float out[3]); /* nvVector.h:376-380 */
+float orc_dot(const float a[3], const float b[3]);  /* nvVector.h:501-507 */
+float orc_length(const float a[3]);
 
 /* PathTracer (PathTracer.cpp:12-44 + MCRenderer.cpp:149-224); rgb_sum[W*H*3] receives the SUM over
  * samples [spp_begin, spp_begin+spp_count); counter RNG keyed (seed, pixel, sample, dim).

@@ -56,7 +56,8 @@ MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_s
                 "mirt_render_pt_dev", "mirt_capture_rays_dev", "mirt_device_info"]
 MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
-                 "mirth_describe", "mirth_upload", "mirth_render", "mirth_fill_intersect", "mirth_test_visibility", "mirth_shutdown",
+                 "mirth_describe", "mirth_upload", "mirth_render", "mirth_fill_intersect", "mirth_test_visibility", "mirth_world_vertex", "mirth_normal_transform",
+                 "mirth_shutdown",
                  "mirth_save_pfm", "mirth_load_pfm"]
 
 _lib = None
@@ -119,6 +120,10 @@ def lib():
         L.mirth_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(RenderStats)]
         L.mirth_fill_intersect.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 8
         L.mirth_test_visibility.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
+        L.mirth_world_vertex.argtypes = [C.c_void_p] * 3
+        L.mirth_world_vertex.restype = None
+        L.mirth_normal_transform.argtypes = [C.c_void_p] * 3
+        L.mirth_normal_transform.restype = None
         L.mirth_save_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         L.mirth_load_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32 * 2)]
         _lib = L

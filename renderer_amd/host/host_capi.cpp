@@ -254,6 +254,23 @@ int mirth_test_visibility(MirthScene* s, size_t n, const float* o, const float* 
     })
 }
 
+// the host math layer, exposed so tests can pin it against the reference's own headers
+void mirth_world_vertex(const float m[16], const float v[3], float out[3]) {
+    matrix4 M;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) M(r, c) = m[r * 4 + c];
+    vec3f p = M.apply(vec3f(v[0], v[1], v[2]), 1.f);
+    out[0] = p.x, out[1] = p.y, out[2] = p.z;
+}
+
+void mirth_normal_transform(const float m[16], const float vn[3], float out[3]) {
+    matrix4 M;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) M(r, c) = m[r * 4 + c];
+    vec3f p = M.inverse().transposed().apply(vec3f(vn[0], vn[1], vn[2]), 0.f);
+    out[0] = p.x, out[1] = p.y, out[2] = p.z;
+}
+
 void mirth_shutdown(void) { IntersectionHIP::shutdown(); }
 
 int mirth_save_pfm(const char* path, const float* rgb, int32_t w, int32_t h) {
