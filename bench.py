@@ -47,7 +47,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pt-spp", type=int, default=32, help="spp of the path-tracing section (whole job)")
+    ap.add_argument("--pt-spp", type=int, default=4096,
+                    help="spp of the path-tracing section, whole job (BASELINE.json configs[2]: 1024x1024 x 4096 spp)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--workload", choices=("cornell", "mesh1m", "fog"), default="cornell",
                     help="cornell = BASELINE.json configs[1] (the headline); mesh1m = SURVEY.md C4, three "

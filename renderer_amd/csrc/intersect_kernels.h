@@ -71,7 +71,10 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
 // is exactly "closest legal hit is nearer than the limit" because the rounded difference is
 // monotone in t. The traversal stops at the first such hit and never enters boxes beyond the limit.
 template <int MODE, bool COUNT, bool SLOT_OUT, bool ANYHIT = false>
-__global__ void __launch_bounds__(256)
+#ifndef MIRT_WAVES_PER_EU
+#define MIRT_WAVES_PER_EU 5
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_WAVES_PER_EU, MIRT_WAVES_PER_EU)))
 k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ D,
             const int* __restrict__ aux, uint32_t n_direct, const uint32_t* __restrict__ n_ptr,
             uint32_t plane_stride, float* __restrict__ t_out,
@@ -110,6 +113,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     pre.inv = mk3(0, 0, 0);
     pre.a_ray = 0.f;
     pre.fast = false;
+    RayPre2 pre2 = ray_pairs(o, pre);
 
     // does the box pass the reference test? Decided by the slab classifier when it can prove the
     // answer, by the reference arithmetic itself (box_test) otherwise: rarely taken, so whole waves
@@ -192,6 +196,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 has = false;
                 active = true;
                 pre = ray_prepare(sc, o, d);
+                pre2 = ray_pairs(o, pre);
                 float lb;
                 const int code = slab_classify(sc.root_lo, sc.root_hi, box_is_flat(sc.root_lo, sc.root_hi), o, pre, lb);
                 if (resolve(sc.root_lo, sc.root_hi, code, lb)) enter(__float_as_int(sc.root_lo.w));
@@ -215,16 +220,16 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             }
             const PairRec P = sc.pairs[link];
             float lbl, lbr;
-            const int cl = slab_classify(P.llo, P.lhi, __float_as_int(P.lhi.w) != 0, o, pre, lbl);
-            const int cr = slab_classify(P.rlo, P.rhi, __float_as_int(P.rhi.w) != 0, o, pre, lbr);
+            const int cl = slab_classify_pair(P.la, P.lb, pre2, pre, lbl);
+            const int cr = slab_classify_pair(P.ra, P.rb, pre2, pre, lbr);
             bool vl = cl == BOX_HIT, vr = cr == BOX_HIT;
             if (COUNT || !pre.fast || cl == BOX_AMBIGUOUS || cr == BOX_AMBIGUOUS) {
-                vl = resolve(P.llo, P.lhi, cl, lbl);
-                vr = resolve(P.rlo, P.rhi, cr, lbr);
+                vl = resolve(pair_lo(P.la, P.lb), pair_hi(P.la, P.lb), cl, lbl);
+                vr = resolve(pair_lo(P.ra, P.rb), pair_hi(P.ra, P.rb), cr, lbr);
             }
             vl &= !(lbl > thr);
             vr &= !(lbr > thr);
-            const int kl = __float_as_int(P.llo.w), kr = __float_as_int(P.rlo.w);
+            const int kl = __float_as_int(P.lb.z), kr = __float_as_int(P.rb.z);
             const bool pick_l = vl & (!vr | (lbl <= lbr));  // nearer child first
             if (vl & vr) {
                 const uint2 e = make_uint2((uint32_t)(pick_l ? kr : kl), __float_as_uint(pick_l ? lbr : lbl));

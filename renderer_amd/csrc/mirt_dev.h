@@ -23,13 +23,23 @@ struct NodeRec {  // (unused by the kernels since the pair layout; kept for tool
     float4 lo, hi;
 };
 // traversal record, 64 B: the two children of one inner node, in BREADTH-FIRST order of the inner
-// nodes (the top of the tree is contiguous). Per child: (min.xyz, bits link), (max.xyz, bits flat)
+// nodes (the top of the tree is contiguous). Per child two float4, with each axis' two planes side
+// by side so that the slab parameters come out of packed fp32 instructions (v_pk_add_f32 /
+// v_pk_mul_f32 on the register pair a dwordx4 load leaves behind, no moves):
+//   a = (min.x, max.x, min.y, max.y)    b = (min.z, max.z, bits link, bits flat)
 //   flat != 0: the box has zero extent along at least one axis (slab_classify)
 //   link >= 0: index of the child's own PairRec (inner node)
 //   link <  0: leaf, ~link = first slot | (triangle count << 24)
 struct PairRec {
-    float4 llo, lhi, rlo, rhi;
+    float4 la, lb, ra, rb;
 };
+// the (min.xyz, link) / (max.xyz, flat) view of one child, as box_test and the root record use it
+__host__ __device__ __forceinline__ float4 pair_lo(const float4 a, const float4 b) { return make_float4(a.x, a.z, b.x, b.z); }
+__host__ __device__ __forceinline__ float4 pair_hi(const float4 a, const float4 b) { return make_float4(a.y, a.w, b.y, b.w); }
+__host__ __device__ __forceinline__ void pair_pack(const float4 lo, const float4 hi, float4* a, float4* b) {
+    *a = make_float4(lo.x, hi.x, lo.y, hi.y);
+    *b = make_float4(lo.z, hi.z, lo.w, hi.w);
+}
 // triangle record in SLOT (leaf) order, 48 B: positions + the unit plane normal the reference
 // recomputes per test (KDTree.cpp:283-284), precomputed on the host with identical arithmetic.
 //   a = (v0, n.x)  b = (v1, n.y)  c = (v2, n.z)
@@ -215,6 +225,39 @@ __device__ __forceinline__ int slab_classify(const float4 lo, const float4 hi, b
     const bool on_flat = flat & (tn == tf);
     const bool ok_gap = (gap > M) | on_flat;
     // the face that decides the hit: the exit face, or (origin outside) the entry face as well
+    const float e = tn >= 0.f ? fmaxf(e_top, e_bot) : e_bot;
+    const bool hit = ok_gap & (tf >= 0.f) & (e > M);
+    const bool miss = (tf < -M) | (fminf(fminf(-gap, e_top), e_bot) > M) | (on_flat & (tf < 0.f));
+    return hit ? BOX_HIT : (miss ? BOX_MISS : BOX_AMBIGUOUS);
+}
+// the same decision on a PairRec child (planes of one axis adjacent): identical operations and
+// roundings, two at a time
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct RayPre2 {
+    v2f oxy, ozz, ixy, izz;  // origin / reciprocal direction as register pairs (broadcast by op_sel)
+};
+__device__ __forceinline__ RayPre2 ray_pairs(f3 o, const RayPre& p) {
+    RayPre2 q;
+    q.oxy = v2f{o.x, o.y}, q.ozz = v2f{o.z, o.z};
+    q.ixy = v2f{p.inv.x, p.inv.y}, q.izz = v2f{p.inv.z, p.inv.z};
+    return q;
+}
+__device__ __forceinline__ int slab_classify_pair(const float4 a, const float4 b, const RayPre2& q,
+                                                  const RayPre& p, float& lb) {
+    const v2f tx = (v2f{a.x, a.y} - q.oxy.xx) * q.ixy.xx;
+    const v2f ty = (v2f{a.z, a.w} - q.oxy.yy) * q.ixy.yy;
+    const v2f tz = (v2f{b.x, b.y} - q.ozz.xx) * q.izz.xx;
+    const float nx = fminf(tx.x, tx.y), fx = fmaxf(tx.x, tx.y);
+    const float ny = fminf(ty.x, ty.y), fy = fmaxf(ty.x, ty.y);
+    const float nz = fminf(tz.x, tz.y), fz = fmaxf(tz.x, tz.y);
+    const float tn = fmaxf(nx, fmaxf(ny, nz)), n2 = __builtin_amdgcn_fmed3f(nx, ny, nz);
+    const float tf = fminf(fx, fminf(fy, fz)), f2 = __builtin_amdgcn_fmed3f(fx, fy, fz);
+    const float M = __builtin_fmaf(1.9073486e-06f /*32 * 2^-24*/, fabsf(tn) + fabsf(tf), p.a_ray);
+    const float gap = tf - tn, e_top = tn - n2, e_bot = f2 - tf;
+    lb = fmaxf(tn, 0.f);
+    const bool flat = __float_as_int(b.w) != 0;
+    const bool on_flat = flat & (tn == tf);
+    const bool ok_gap = (gap > M) | on_flat;
     const float e = tn >= 0.f ? fmaxf(e_top, e_bot) : e_bot;
     const bool hit = ok_gap & (tf >= 0.f) & (e > M);
     const bool miss = (tf < -M) | (fminf(fminf(-gap, e_top), e_bot) > M) | (on_flat & (tf < 0.f));

@@ -176,9 +176,10 @@ __device__ inline float trace_object(const DevScene& sc, const VolRoot& R, f3 o,
     while (has) {
         if (link >= 0) {
             const PairRec P = sc.pairs[link];
-            const BoxHit bl = box_test(P.llo, P.lhi, o, d), br = box_test(P.rlo, P.rhi, o, d);
+            const BoxHit bl = box_test(pair_lo(P.la, P.lb), pair_hi(P.la, P.lb), o, d),
+                         br = box_test(pair_lo(P.ra, P.rb), pair_hi(P.ra, P.rb), o, d);
             const bool vl = bl.hit && !(bl.lb > thr), vr = br.hit && !(br.lb > thr);
-            const int kl = __float_as_int(P.llo.w), kr = __float_as_int(P.rlo.w);
+            const int kl = __float_as_int(P.lb.z), kr = __float_as_int(P.rb.z);
             const bool pick_l = vl && (!vr || bl.lb <= br.lb);
             if (vl && vr) {
                 stk[sp] = make_uint2((uint32_t)(pick_l ? kr : kl), __float_as_uint(pick_l ? br.lb : bl.lb));

@@ -61,3 +61,8 @@ if os.environ.get("SORTEXP"):
             a = dev.intersect_audit_dev(o2.data_ptr(), d2.data_ptr(), a2.data_ptr(), n, 2, t1.data_ptr(), i1.data_ptr())
             print("   inner lane util %.3f  leaf lane util %.3f" % ((a["box"] / 2) / (64.0 * a["wave_inner"]), a["tri"] / (64.0 * a["wave_leaf"])))
         del o2, d2, a2
+if os.environ.get("SWEEP"):
+    # launch-size sweep: where is the latency floor of a small launch?
+    for n in (64, 1024, 8192, 65536, 262144, 1 << 20, 1 << 22):
+        ms = run(so, sd, sa.data_ptr(), n, 2)
+        print("n %8d  %.4f ms  (%.1f Mrays/s)" % (n, ms, n / ms / 1e3), flush=True)
