@@ -139,6 +139,7 @@ typedef struct MirtRenderStats {
     uint64_t n_rays;         /* closest-hit queries issued (primary + secondary)             */
     double   gpu_ms;         /* device time of the whole call, HIP events                    */
     double   intersect_ms;   /* device time spent in the intersect kernel, HIP events        */
+    uint64_t n_shadow_rays;  /* visibility queries issued (mirt_render_pttest only)          */
 } MirtRenderStats;
 
 /* --- context ------------------------------------------------------------------------------
@@ -209,6 +210,17 @@ int mirt_render_pt(MirtContext* ctx, const MirtRenderParams* params, float* rgb_
 /* DEVICE pointer version ADDS into rgb_sum (so a multi-call / multi-GPU caller can reduce). */
 int mirt_render_pt_dev(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
                        MirtRenderStats* stats /* may be NULL */);
+/* replaces PathTracerTest::renderPixels + colorByConnectingLights (PathTracerTest.cpp:7-135), the
+ * reference's cross-check integrator ("PTtest", ConfigManager.cpp:285-288): the same eye paths,
+ * plus one connection to the emission sampler (Scene.cpp:91-98, SceneObject.cpp:137-160) per RANDOM
+ * vertex, tested with MCRenderer::testVisibility (one any-hit launch per bounce) and combined with
+ * emitter hits by the balance heuristic. No vignetting compensation (the reference applies none
+ * there). Scenes that hold a medium are refused (MIRT_E_INVALID). Same buffers / semantics as
+ * mirt_render_pt / mirt_render_pt_dev; stats->n_shadow_rays counts the visibility queries.      */
+int mirt_render_pttest(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
+                       MirtRenderStats* stats /* may be NULL */);
+int mirt_render_pttest_dev(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
+                           MirtRenderStats* stats /* may be NULL */);
 
 /* Secondary-ray capture for the closest-hit benchmark: run the path tracer
  * for spp_count samples and copy out every secondary ray (origin, direction, packed ids) issued at

@@ -461,7 +461,9 @@ struct PRay {
     int insideObject, contactObject, intersectObject;  // object ids, -1 = NULL
     unsigned contactObjectTriangleID, intersectObjectTriangleID;
     float intersectDist;
+    bool randomDir;  // directionSampleType == Ray::RANDOM (the Ray.h:46 default)
     PRay() {  // Ray.h:37-51
+        randomDir = true;
         insideObject = intersectObject = contactObject = -1;
         color = V3(1, 1, 1);
         directionProb = 1;
@@ -595,6 +597,7 @@ struct Tracer {
             out.direction = in.direction;
             out.directionProb = 1;
             out.color = V3(1, 1, 1);
+            out.randomDir = false;  // DiffuseMaterial.cpp:42
             return out;
         }
         float dx = rng.genFloat(), dy = rng.genFloat();
@@ -686,6 +689,7 @@ struct Tracer {
         V3 reflDir = -dot(normal, in.direction) * normal * 2 + in.direction;
         out.contactObject = object;
         out.contactObjectTriangleID = in.intersectObjectTriangleID;
+        out.randomDir = false;  // RefractiveMaterial.cpp:31
         if (o.ior < 0) {  // mirror
             out.direction = reflDir;
             out.insideObject = in.insideObject;
@@ -1041,6 +1045,7 @@ struct Tracer {
         termRay.direction = V3(0, 0, 0);
         termRay.color = V3(0, 0, 0);
         termRay.directionProb = 1;
+        termRay.randomDir = false;  // MCRenderer.cpp:160
         termRay.insideObject = termRay.contactObject = termRay.intersectObject = -1;
 
         path.push_back(prevRay);
@@ -1096,6 +1101,211 @@ struct Tracer {
             }
         }
         return eliminateVignetting(color, p);
+    }
+
+    // ---- PathTracerTest (PathTracerTest.cpp:7-135): path tracing + one light connection per
+    // RANDOM vertex, combined with the power-1 balance heuristic. Restated for scenes without media.
+    // Emission sampler: Scene::preprocessEmissionSampler (Scene.cpp:193-204),
+    // SurfaceSampler::preprocess / genSample (Scene.cpp:19-33, 91-98), SceneObject::
+    // preprocessEmissionSampler / emit (SceneObject.cpp:11-21, 137-218), SimpleShape::getTriangleArea /
+    // genRandTrianglePosition (SimpleShape.cpp:14-42).
+    struct Emitters {
+        std::vector<int> objects;             // emissive objects in scene order
+        std::vector<float> weightValues;      // running sum of the un-normalised weights (= areas)
+        std::vector<std::vector<float>> areaValues;  // per object: running sum of triangle areas
+        std::vector<float> totalArea, weight;  // per object; weight after normalizeEmissionWeight
+        float totalWeight = 0;
+    };
+    float triangleArea(unsigned tid) const {
+        V3 vps[3];
+        for (int i = 0; i < 3; i++) vps[i] = S.verts[S.tris[tid].v[i]];
+        V3 l0 = vps[1] - vps[0];
+        V3 l1 = vps[2] - vps[1];
+        return length(cross(l0, l1)) / 2;
+    }
+    Emitters preprocessEmissionSampler() const {
+        Emitters E;
+        for (int i = 0; i < (int)S.objects.size(); i++) {
+            const OrcObject& o = S.objects[i];
+            if (o.type != ORC_EMISSIVE) continue;
+            E.objects.push_back(i);
+            float totalArea = 0;
+            std::vector<float> av;
+            for (int k = 0; k < o.tri_count; k++) {
+                totalArea += triangleArea(o.tri_begin + k);
+                av.push_back(totalArea);
+            }
+            E.areaValues.push_back(av);
+            E.totalArea.push_back(totalArea);
+            E.weight.push_back(totalArea);
+            E.totalWeight += totalArea;
+            E.weightValues.push_back(E.totalWeight);
+        }
+        for (size_t i = 0; i < E.weight.size(); i++) E.weight[i] /= E.totalWeight;
+        return E;
+    }
+    static uint32_t connectionKey(uint32_t key) { return lowbias32(key ^ 0x5bd1e995U); }
+
+    // colorByConnectingLights (PathTracerTest.cpp:85-135) for vertex `ray` reached from `lastRay`;
+    // six draws of the connection stream starting at 6 * vertexIndex (object, triangle, two for the
+    // point, two for the emitted direction, which the connection overwrites)
+    V3 colorByConnectingLights(const Emitters& E, const PRay& ray, const PRay& lastRay, Stream& crng) {
+        if (E.objects.empty()) return V3(0, 0, 0);
+        // SurfaceSampler::genSample
+        float rnd = crng.genFloat() * E.totalWeight;
+        size_t index = std::lower_bound(E.weightValues.begin(), E.weightValues.end(), rnd) - E.weightValues.begin();
+        if (index >= E.weightValues.size()) index = E.weightValues.size() - 1;
+        const int lobj = E.objects[index];
+        // SceneObject::emit(isUniformOrigin = true, ...)
+        PRay lightRay;
+        const std::vector<float>& av = E.areaValues[index];
+        rnd = crng.genFloat() * E.totalArea[index];
+        size_t ti = std::lower_bound(av.begin(), av.end(), rnd) - av.begin();
+        if (ti >= av.size()) ti = av.size() - 1;
+        lightRay.contactObject = lobj;
+        lightRay.contactObjectTriangleID = (unsigned)ti;
+        {
+            V3 vps[3];
+            const unsigned tid = globalTid(lobj, (unsigned)ti);
+            for (int i = 0; i < 3; i++) vps[i] = S.verts[S.tris[tid].v[i]];
+            float u1 = crng.genFloat();
+            float u2 = crng.genFloat();
+            float su1 = sqrtf(u1);
+            float u = 1.f - su1;
+            float v = u2 * su1;
+            lightRay.origin = vps[0] * u + vps[1] * v + vps[2] * (1.f - u - v);
+        }
+        lightRay.originProb = E.weight[index] / E.totalArea[index];
+        crng.genFloat();  // the cosine-sampled emission direction (SceneObject.cpp:183) is replaced below;
+        crng.genFloat();  // it was flipped to the normal's side, so getBSDF(ray, ray) returned the colour
+        const OrcObject& lo = S.objects[lobj];
+        lightRay.color = V3(lo.color[0], lo.color[1], lo.color[2]);
+
+        lightRay.direction = ray.origin - lightRay.origin;
+        float dist = length(lightRay.direction);
+        float dist2 = dist * dist;
+        normalize(lightRay.direction);
+        PRay outRay = ray;
+        outRay.direction = -lightRay.direction;
+
+        // MCRenderer::testVisibility(outRay, lightRay), MCRenderer.cpp:115-117
+        {
+            Condition cond;
+            cond.mode = 2;
+            cond.contact = outRay.contactObject;
+            cond.inside = outRay.insideObject;
+            int oid = -1;
+            unsigned lt = 0;
+            float d = sceneIntersect(outRay, &cond, oid, lt);
+            if (!(d < 0 || (d - length(outRay.origin - lightRay.origin) >= -1e-5f))) return V3(0, 0, 0);
+        }
+        V3 bsdfFactor = getBSDF(lastRay, outRay);
+        if (lumY(bsdfFactor) < 1e-7f) return V3(0, 0, 0);
+        float cosAtLight = std::min(std::max(0.f, std::abs(dot(contactNormal(lightRay), lightRay.direction))), 1.f);
+        if (cosAtLight < 1e-6f) return V3(0, 0, 0);
+        float cosToLight = 1;
+        if (ray.contactObject != -1)
+            cosToLight = std::min(std::max(0.f, std::abs(dot(contactNormal(ray), -lightRay.direction))), 1.f);
+        float bsdfToLightPdf = directionSampleProbDensity(lastRay, outRay);
+        float lightOriginPdf = lightRay.originProb;
+        float dirPdfW = lightOriginPdf * dist2 / cosAtLight;
+        float mis = dirPdfW / (dirPdfW + bsdfToLightPdf);
+        V3 tmp = lightRay.color * cosAtLight * bsdfFactor * cosToLight / (lightRay.originProb * dist2);
+        return tmp * mis;
+    }
+    // Ray::getBSDF (Ray.cpp:14-26) -> SceneObject::getBSDF (SceneObject.cpp:341-352) -> the material's:
+    // DiffuseMaterial.cpp:94-101 / DiffuseBSDF.h:18-24, GlossyMaterial.cpp:69-79 / GlossyBSDF.h:24-33
+    // (scaled by max(colour), as the reference does), Material.h:20 (zero) for the refractive ones,
+    // SceneEmissiveObject.cpp:21-26
+    V3 getBSDF(const PRay& inRay, const PRay& outRay) const {
+        if (outRay.contactObject < 0) return V3(0, 0, 0);  // (no media here; the camera is never a vertex >= 1)
+        const OrcObject& o = S.objects[outRay.contactObject];
+        V3 color(o.color[0], o.color[1], o.color[2]);
+        if (o.type == ORC_EMISSIVE) return dot(contactNormal(outRay), outRay.direction) < 0 ? V3(0, 0, 0) : color;
+        LocalFrame lf;
+        lf.buildFromNormal(objNormal(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin));
+        if (o.type == ORC_DIFFUSE) {
+            if (dot(lf.n, inRay.direction) <= 0 && dot(lf.n, outRay.direction) >= 0) return color / float(REF_PI);
+            return V3(0, 0, 0);
+        }
+        if (o.type == ORC_GLOSSY) {
+            float p = std::max(color.x, std::max(color.y, color.z));
+            V3 c(0, 0, 0);
+            if (dot(lf.n, inRay.direction) <= 0 && dot(lf.n, outRay.direction) >= 0) {
+                V3 r2 = -dot(lf.n, inRay.direction) * lf.n * 2 + inRay.direction;
+                if (dot(r2, outRay.direction) > 0) c = color * powf(dot(r2, outRay.direction), o.coeff);
+            }
+            return p * c;
+        }
+        return V3(0, 0, 0);
+    }
+    // Ray::getDirectionSampleProbDensity (Ray.cpp:28-40) -> SceneObject.cpp:227-248 -> the material's:
+    // DiffuseMaterial.cpp:78-86, GlossyMaterial.cpp:58-67, Material.h:18 (1) for refractive objects;
+    // an emissive object has no material (0)
+    float directionSampleProbDensity(const PRay& inRay, const PRay& outRay) const {
+        if (outRay.contactObject < 0) return 0;
+        const OrcObject& o = S.objects[outRay.contactObject];
+        if (o.type == ORC_DIFFUSE) {
+            LocalFrame lf;
+            lf.buildFromNormal(objNormal(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin));
+            float p = std::max(o.color[0], std::max(o.color[1], o.color[2]));
+            return p * cosPdf(lf, outRay.direction, 1.f);
+        }
+        if (o.type == ORC_GLOSSY) {
+            LocalFrame lf;
+            V3 normal = contactNormal(outRay);
+            V3 reflDir = -dot(normal, inRay.direction) * normal * 2 + inRay.direction;
+            lf.buildFromNormal(reflDir);
+            return cosPdf(lf, outRay.direction, o.coeff);
+        }
+        if (o.type == ORC_REFRACTIVE) return 1;
+        return 0;
+    }
+
+    // PathTracerTest.cpp:20-78 for one (pixel, sample)
+    V3 samplePixelTest(const Emitters& E, unsigned p, unsigned s, uint32_t seed, std::vector<PRay>& eyePath,
+                       uint64_t* shadowRays) {
+        Stream rng(seed, p, s);
+        eyePath.clear();
+        PRay start = generateRay(p, rng);
+        samplePath(eyePath, start, 0, rng);
+        V3 throughput(1, 1, 1), color(0, 0, 0);
+        bool lastSpecular = true;
+        float lastPdfW = 1.f;
+        for (size_t i = 1; i < eyePath.size(); i++) {
+            const PRay& v = eyePath[i];
+            if (emissive(v.contactObject)) {
+                const OrcObject& eo = S.objects[v.contactObject];
+                V3 contrib(eo.color[0], eo.color[1], eo.color[2]);
+                size_t ei = std::find(E.objects.begin(), E.objects.end(), v.contactObject) - E.objects.begin();
+                float dirPdfA = E.weight[ei] / E.totalArea[ei];
+                float mis = 1.f;
+                if (i > 1 && !lastSpecular) {
+                    float cosine = dot(contactNormal(v), -eyePath[i - 1].direction);
+                    float dist = length(v.origin - eyePath[i - 1].origin);
+                    float dirPdfW = dirPdfA * dist * dist / std::abs(cosine);
+                    mis = lastPdfW / (lastPdfW + dirPdfW);
+                }
+                color = color + throughput * contrib * mis;
+                break;
+            }
+            if (v.randomDir) {
+                Stream crng(seed, p, s);
+                crng.key = connectionKey(crng.key);
+                crng.ctr = 6 * (uint32_t)i;
+                if (shadowRays) (*shadowRays)++;
+                color = color + throughput * colorByConnectingLights(E, v, eyePath[i - 1], crng);
+            }
+            if (i + 1 >= eyePath.size() || (v.origin.x == eyePath[i + 1].origin.x && v.origin.y == eyePath[i + 1].origin.y &&
+                                            v.origin.z == eyePath[i + 1].origin.z))
+                break;
+            lastSpecular = !v.randomDir;
+            lastPdfW = v.directionProb;
+            throughput = throughput * (v.color * cosineTerm(v) / v.directionProb);
+            float dist = std::max(length(v.origin - eyePath[i - 1].origin), 1e-5f);
+            throughput = throughput * radianceDecay(eyePath[i - 1], dist);
+        }
+        return color;
     }
 };
 
@@ -1370,6 +1580,39 @@ void orc_render_pt(const OrcScene* s, const OrcCamera* cam, uint32_t spp_begin, 
         total += tr.nRays;
     }
     if (n_rays) *n_rays = total;
+}
+
+int orc_render_pttest(const OrcScene* s, const OrcCamera* cam, uint32_t spp_begin, uint32_t spp_count,
+                      uint32_t max_depth, uint32_t seed, float* rgb_sum, uint64_t* n_rays,
+                      uint64_t* n_shadow_rays, int threads) {
+    for (const OrcObject& o : s->objects)
+        if (o.type == ORC_VPM) return -1;  // restated for scenes without media
+    int npix = cam->width * cam->height;
+    std::fill(rgb_sum, rgb_sum + 3 * (size_t)npix, 0.f);
+    uint64_t total = 0, shadows = 0;
+#pragma omp parallel num_threads(threads > 0 ? threads : 1) reduction(+ : total, shadows)
+    {
+        Tracer tr(*s, *cam, max_depth);
+        const Tracer::Emitters E = tr.preprocessEmissionSampler();
+        std::vector<PRay> path;
+#pragma omp for schedule(dynamic, 64)
+        for (int p = 0; p < npix; p++) {
+            float acc[3] = {0, 0, 0};
+            for (uint32_t k = 0; k < spp_count; k++) {
+                V3 c = tr.samplePixelTest(E, (unsigned)p, spp_begin + k, seed, path, &shadows);
+                acc[0] += c.x;
+                acc[1] += c.y;
+                acc[2] += c.z;
+            }
+            rgb_sum[3 * p] = acc[0];
+            rgb_sum[3 * p + 1] = acc[1];
+            rgb_sum[3 * p + 2] = acc[2];
+        }
+        total += tr.nRays;
+    }
+    if (n_rays) *n_rays = total - shadows;
+    if (n_shadow_rays) *n_shadow_rays = shadows;
+    return 0;
 }
 
 int32_t orc_trace_path(const OrcScene* s, const OrcCamera* cam, uint32_t pixel, uint32_t sample,

@@ -118,6 +118,13 @@ float orc_length(const float a[3]);
 void orc_render_pt(const OrcScene* s, const OrcCamera* cam, uint32_t spp_begin, uint32_t spp_count,
                    uint32_t max_depth, uint32_t seed, float* rgb_sum, uint64_t* n_rays,
                    int threads);
+/* PathTracerTest (PathTracerTest.cpp:7-135): the same paths plus one light connection per RANDOM
+ * vertex, balance-heuristic MIS; no vignetting compensation (the reference applies none there).
+ * Connection draws come from a second stream of the same (seed, pixel, sample): key' =
+ * lowbias32(key ^ 0x5bd1e995), draw 6*vertexIndex + j. Returns -1 for scenes that hold a medium. */
+int orc_render_pttest(const OrcScene* s, const OrcCamera* cam, uint32_t spp_begin, uint32_t spp_count,
+                      uint32_t max_depth, uint32_t seed, float* rgb_sum, uint64_t* n_rays,
+                      uint64_t* n_shadow_rays, int threads);
 /* one path, verbose: writes up to cap vertices (origin xyz, dir xyz, color rgb, dirProb) = 10
  * floats each; returns the vertex count and the path's contribution in rgb[3].                 */
 int32_t orc_trace_path(const OrcScene* s, const OrcCamera* cam, uint32_t pixel, uint32_t sample,

@@ -38,7 +38,7 @@ class RenderParams(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("n_samples", C.c_uint64), ("n_rays", C.c_uint64), ("gpu_ms", C.c_double),
-                ("intersect_ms", C.c_double)]
+                ("intersect_ms", C.c_double), ("n_shadow_rays", C.c_uint64)]
 
 
 class SceneDesc(C.Structure):
@@ -53,7 +53,7 @@ class SceneDesc(C.Structure):
 # every symbol include/mirt.h and include/mirt_host.h declare (checked by the CPU tests)
 MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_scene", "mirt_intersect",
                 "mirt_intersect_dev", "mirt_visibility", "mirt_visibility_dev", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
-                "mirt_render_pt_dev", "mirt_capture_rays_dev", "mirt_device_info"]
+                "mirt_render_pt_dev", "mirt_render_pttest", "mirt_render_pttest_dev", "mirt_capture_rays_dev", "mirt_device_info"]
 MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
                  "mirth_describe", "mirth_upload", "mirth_render", "mirth_fill_intersect", "mirth_test_visibility", "mirth_world_vertex", "mirth_normal_transform",
@@ -103,6 +103,8 @@ def lib():
                                              C.c_void_p, C.c_void_p]
         L.mirt_render_pt.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
         L.mirt_render_pt_dev.argtypes = L.mirt_render_pt.argtypes
+        L.mirt_render_pttest.argtypes = L.mirt_render_pt.argtypes
+        L.mirt_render_pttest_dev.argtypes = L.mirt_render_pt.argtypes
         L.mirt_capture_rays_dev.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.c_uint32,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.POINTER(C.c_size_t)]
@@ -341,6 +343,20 @@ class Device:
         st = RenderStats()
         self._check(lib().mirt_render_pt(self.ctx, C.byref(p), _ptr(img), C.byref(st)))
         return img, st
+
+    def render_pttest(self, cam, spp_count, spp_begin=0, max_depth=20, seed=1, spp_per_launch=0):
+        """PathTracerTest (light connections + MIS): (rgb_sum [H, W, 3] float32 on the host, RenderStats)."""
+        p = RenderParams(cam, spp_begin, spp_count, max_depth, seed, spp_per_launch)
+        img = np.zeros((cam.height, cam.width, 3), np.float32)
+        st = RenderStats()
+        self._check(lib().mirt_render_pttest(self.ctx, C.byref(p), _ptr(img), C.byref(st)))
+        return img, st
+
+    def render_pttest_dev(self, cam, rgb_sum_ptr, spp_count, spp_begin=0, max_depth=20, seed=1, spp_per_launch=0):
+        p = RenderParams(cam, spp_begin, spp_count, max_depth, seed, spp_per_launch)
+        st = RenderStats()
+        self._check(lib().mirt_render_pttest_dev(self.ctx, C.byref(p), rgb_sum_ptr, C.byref(st)))
+        return st
 
     def render_pt_dev(self, cam, rgb_sum_ptr, spp_count, spp_begin=0, max_depth=20, seed=1, spp_per_launch=0):
         p = RenderParams(cam, spp_begin, spp_count, max_depth, seed, spp_per_launch)

@@ -35,6 +35,9 @@ struct MirtContext {
     bool has_media = false;    // scene holds a homogeneous medium (MIRT_OBJ_VPM)
     bool media_ready = true;   // ... and every such object came with its own tree
     VolRoot* d_vols = nullptr;
+    DevLight* d_lights = nullptr;   // emission sampler tables (PathTracerTest)
+    float* d_light_area = nullptr;
+    int* d_light_slot = nullptr;
     int block = 256;
     size_t lds_main = 0;   // the first lds_levels stack levels live in LDS, deeper ones in d_spill
     uint32_t lds_levels = 0;
@@ -43,6 +46,10 @@ struct MirtContext {
     PathBuf pb[2]{};
     size_t pb_cap = 0;
     float* d_L = nullptr;
+    ShadowBuf shb{};             // PathTracerTest: shadow rays of the running bounce
+    size_t shb_cap = 0;
+    uint32_t* d_ns = nullptr;    // [cnt_cap] shadow rays written by bounce k
+    uint32_t* d_wq2 = nullptr;   // [cnt_cap] ray-queue heads of the visibility launches
     uint32_t* d_cnt = nullptr;   // [cnt_cap] live paths after k bounces of the running wavefront
     uint32_t* d_wq = nullptr;    // [cnt_cap] ray-queue heads, one per intersect launch of the wavefront
     uint32_t* h_cnt = nullptr;   // pinned, [cnt_cap]
@@ -160,6 +167,12 @@ static void free_scene(MirtContext* ctx) {
     ctx->d_spill = nullptr;
     hipFree(ctx->d_vols);
     ctx->d_vols = nullptr;
+    hipFree(ctx->d_lights);
+    hipFree(ctx->d_light_area);
+    hipFree(ctx->d_light_slot);
+    ctx->d_lights = nullptr;
+    ctx->d_light_area = nullptr;
+    ctx->d_light_slot = nullptr;
     ctx->d_tris = nullptr;
     ctx->d_vns = nullptr;
     ctx->d_objs = nullptr;
@@ -170,12 +183,16 @@ static void free_paths(MirtContext* ctx) {
     for (int k = 0; k < 2; k++) {
         PathBuf& p = ctx->pb[k];
         hipFree(p.o); hipFree(p.d); hipFree(p.thr); hipFree(p.t); hipFree(p.slot);
-        hipFree(p.key); hipFree(p.ctr); hipFree(p.ids); hipFree(p.pid);
+        hipFree(p.key); hipFree(p.ctr); hipFree(p.ids); hipFree(p.pid); hipFree(p.lpw);
         p = PathBuf{};
     }
     hipFree(ctx->d_L);
     ctx->d_L = nullptr;
     ctx->pb_cap = 0;
+    ShadowBuf& b = ctx->shb;
+    hipFree(b.o); hipFree(b.d); hipFree(b.ids); hipFree(b.lim); hipFree(b.c); hipFree(b.pid); hipFree(b.vis);
+    b = ShadowBuf{};
+    ctx->shb_cap = 0;
 }
 
 static void free_staging(MirtContext* ctx) {
@@ -196,6 +213,8 @@ int mirt_destroy(MirtContext* ctx) {
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     hipFree(ctx->d_cnt);
     hipFree(ctx->d_wq);
+    hipFree(ctx->d_ns);
+    hipFree(ctx->d_wq2);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_queue);
     if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
@@ -499,6 +518,49 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
             d.sigma_t[c] = m.sigma_s[c] + m.sigma_a[c];  // SceneVPMObject.h:82-86: dt = ds + da
         }
         d.g = m.g;
+        d.emit_pdf_a = 0.f;
+    }
+    // Emission sampler (Scene::preprocessEmissionSampler, Scene.cpp:193-204 -> SurfaceSampler::preprocess,
+    // Scene.cpp:19-33 -> SceneObject::preprocessEmissionSampler, SceneObject.cpp:11-21): per emissive
+    // object the running triangle areas (SimpleShape::getTriangleArea, SimpleShape.cpp:14-26: |l0 x l1| / 2,
+    // fp32, accumulated in triangle order), weight = totalArea, normalised by the sum over the lights.
+    std::vector<DevLight> lights;
+    std::vector<float> light_area;
+    std::vector<int> light_slot;
+    float light_total_weight = 0.f;
+    {
+        std::vector<int> slot_of(T, -1);
+        for (int k = 0; k < T; k++) slot_of[s->slot_tid[k]] = k;
+        for (int o = 0; o < s->n_objects; o++) {
+            const MirtObject& m = s->objects[o];
+            if (m.type != MIRT_OBJ_EMISSIVE) continue;
+            DevLight L{};
+            L.first = (int)light_area.size();
+            L.count = m.tri_count;
+            L.object = o;
+            float total = 0.f;
+            for (int k = 0; k < m.tri_count; k++) {
+                const float* p = s->tri_pos + 9 * (size_t)(m.tri_begin + k);
+                h3 v0{p[0], p[1], p[2]}, v1{p[3], p[4], p[5]}, v2{p[6], p[7], p[8]};
+                h3 c = hcross(hsub(v1, v0), hsub(v2, v1));
+                float r = 0.f;  // nvVector.h:501-507: r = 0; r += x*x; ...
+                r += c.x * c.x;
+                r += c.y * c.y;
+                r += c.z * c.z;
+                total += sqrtf(r) / 2;
+                light_area.push_back(total);
+                light_slot.push_back(slot_of[m.tri_begin + k]);
+            }
+            L.total_area = total;
+            light_total_weight += total;
+            L.weight_sum = light_total_weight;
+            lights.push_back(L);
+        }
+        for (DevLight& L : lights) {
+            const float weight = L.total_area / light_total_weight;  // normalizeEmissionWeight
+            L.origin_prob = weight / L.total_area;
+            objs[L.object].emit_pdf_a = L.origin_prob;
+        }
     }
 
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -517,6 +579,19 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     }
     ctx->sc.vols = ctx->d_vols;
     ctx->sc.n_vols = n_obj_trees;
+    if (!lights.empty()) {
+        HIPCHK(ctx, hipMalloc(&ctx->d_lights, sizeof(DevLight) * lights.size()));
+        HIPCHK(ctx, hipMemcpy(ctx->d_lights, lights.data(), sizeof(DevLight) * lights.size(), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMalloc(&ctx->d_light_area, sizeof(float) * std::max<size_t>(1, light_area.size())));
+        HIPCHK(ctx, hipMalloc(&ctx->d_light_slot, sizeof(int) * std::max<size_t>(1, light_slot.size())));
+        HIPCHK(ctx, hipMemcpy(ctx->d_light_area, light_area.data(), sizeof(float) * light_area.size(), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->d_light_slot, light_slot.data(), sizeof(int) * light_slot.size(), hipMemcpyHostToDevice));
+    }
+    ctx->sc.lights = ctx->d_lights;
+    ctx->sc.light_area = ctx->d_light_area;
+    ctx->sc.light_slot = ctx->d_light_slot;
+    ctx->sc.n_lights = (int)lights.size();
+    ctx->sc.light_total_weight = light_total_weight;
     HIPCHK(ctx, hipMemcpy(ctx->d_objs, objs.data(), sizeof(DevObject) * (size_t)s->n_objects, hipMemcpyHostToDevice));
     for (int c = 0; c < 3; c++) ctx->sc.bound[c] = bound[c];
     ctx->sc.fast_ok = fast_ok;
@@ -608,15 +683,18 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
 // visibility variant: vis_out[i] = 1 unless a legal hit lies nearer than limit[i]
 static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
                              const int* aux, const float* limit, uint32_t n, uint32_t stride,
-                             unsigned char* vis_out) {
+                             unsigned char* vis_out, const uint32_t* n_ptr = nullptr, uint32_t* queue = nullptr) {
     if (n == 0) return MIRT_OK;
     const uint32_t want = (n + ctx->block - 1) / ctx->block;
     dim3 block(ctx->block), grid(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), st));
+    if (!queue) {
+        queue = ctx->d_queue;
+        HIPCHK(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), st));
+    }
 #define MIRT_VIS(MODE)                                                                                        \
     hipLaunchKernelGGL((k_intersect<MODE, false, false, true>), grid, block, ctx->lds_main, st, ctx->sc, O, D, aux, \
-                       n, (const uint32_t*)nullptr, stride, (float*)nullptr, (int*)nullptr, ctx->d_counters,     \
-                       ctx->d_queue, ctx->lds_levels, ctx->d_spill, limit, vis_out)
+                       n, n_ptr, stride, (float*)nullptr, (int*)nullptr, ctx->d_counters,                        \
+                       queue, ctx->lds_levels, ctx->d_spill, limit, vis_out)
     switch (mode) {
         case MIRT_MODE_UNCONDITIONAL: MIRT_VIS(MIRT_MODE_UNCONDITIONAL); break;
         case MIRT_MODE_LAST_TID: MIRT_VIS(MIRT_MODE_LAST_TID); break;
@@ -813,10 +891,30 @@ static int ensure_paths(MirtContext* ctx, size_t cap) {
         HIPCHK(ctx, hipMalloc(&p.ctr, cap * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc(&p.ids, cap * sizeof(int)));
         HIPCHK(ctx, hipMalloc(&p.pid, cap * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc(&p.lpw, cap * sizeof(float)));
         p.stride = (uint32_t)cap;
     }
     HIPCHK(ctx, hipMalloc(&ctx->d_L, 3 * cap * sizeof(float)));
     ctx->pb_cap = cap;
+    return MIRT_OK;
+}
+
+// shadow-ray buffers of PathTracerTest: at most one light connection per live path and bounce
+static int ensure_shadow(MirtContext* ctx, size_t cap) {
+    if (cap <= ctx->shb_cap) return MIRT_OK;
+    ShadowBuf& b = ctx->shb;
+    hipFree(b.o); hipFree(b.d); hipFree(b.ids); hipFree(b.lim); hipFree(b.c); hipFree(b.pid); hipFree(b.vis);
+    b = ShadowBuf{};
+    ctx->shb_cap = 0;
+    HIPCHK(ctx, hipMalloc(&b.o, 3 * cap * sizeof(float)));
+    HIPCHK(ctx, hipMalloc(&b.d, 3 * cap * sizeof(float)));
+    HIPCHK(ctx, hipMalloc(&b.c, 3 * cap * sizeof(float)));
+    HIPCHK(ctx, hipMalloc(&b.ids, cap * sizeof(int)));
+    HIPCHK(ctx, hipMalloc(&b.lim, cap * sizeof(float)));
+    HIPCHK(ctx, hipMalloc(&b.pid, cap * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&b.vis, cap));
+    b.stride = (uint32_t)cap;
+    ctx->shb_cap = cap;
     return MIRT_OK;
 }
 
@@ -843,7 +941,7 @@ static hipEvent_t get_event(MirtContext* ctx, size_t k) {
 // being captured. *n_rays_dev accumulates the rays traced.
 static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRenderParams* prm,
                          uint32_t s0, uint32_t S, float* rgb_sum, Capture* cap, uint64_t* n_rays,
-                         size_t* ev_used) {
+                         size_t* ev_used, bool nee = false, uint64_t* n_shadow = nullptr) {
     const uint32_t wh = (uint32_t)cam.width * (uint32_t)cam.height;
     const uint32_t P = wh * S;
     hipStream_t st = ctx->stream;
@@ -855,19 +953,27 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
         HIPCHK(ctx, hipStreamSynchronize(st));
         hipFree(ctx->d_cnt);
         hipFree(ctx->d_wq);
+        hipFree(ctx->d_ns);
+        hipFree(ctx->d_wq2);
         hipHostFree(ctx->h_cnt);
-        ctx->d_cnt = ctx->d_wq = ctx->h_cnt = nullptr;
+        ctx->d_cnt = ctx->d_wq = ctx->d_ns = ctx->d_wq2 = ctx->h_cnt = nullptr;
         ctx->cnt_cap = 0;
         HIPCHK(ctx, hipMalloc(&ctx->d_cnt, words * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc(&ctx->d_wq, words * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc(&ctx->d_ns, words * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc(&ctx->d_wq2, words * sizeof(uint32_t)));
         HIPCHK(ctx, hipHostMalloc(&ctx->h_cnt, words * sizeof(uint32_t)));
         ctx->cnt_cap = words;
+    }
+    if (nee) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_ns, 0, words * sizeof(uint32_t), st));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_wq2, 0, words * sizeof(uint32_t), st));
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_L, 0, 3 * ctx->pb_cap * sizeof(float), st));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt, 0, words * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_wq, 0, words * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_generate, dim3((P + B - 1) / B), dim3(B), 0, st, cam, P, s0, prm->seed, cur->o,
-                       cur->d, cur->stride, *cur, 1);
+                       cur->d, cur->stride, *cur, nee ? 2 : 1);
     HIPCHK(ctx, hipGetLastError());
     auto timed_intersect = [&](int mode, PathBuf* pb, uint32_t n, const uint32_t* n_ptr, uint32_t* queue) -> int {
         hipEvent_t e0 = get_event(ctx, *ev_used), e1 = get_event(ctx, *ev_used + 1);
@@ -888,7 +994,20 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
     for (uint32_t depth = 0; depth <= prm->max_depth; depth++) {
         const uint32_t* n_in = depth ? ctx->d_cnt + depth : nullptr;
         uint32_t* n_out = ctx->d_cnt + depth + 1;
-        if (ctx->has_media)
+        if (nee) {
+            // PathTracerTest: shade writes one shadow ray per RANDOM vertex; the visibility launch and
+            // k_connect add the unoccluded contributions before the next bounce touches L again
+            uint32_t* n_sh = ctx->d_ns + depth;
+            hipLaunchKernelGGL((k_shade<false, true>), dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur,
+                               n_in, bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, depth, prm->max_depth,
+                               ctx->shb, n_sh);
+            HIPCHK(ctx, hipGetLastError());
+            int rcv = launch_visibility(ctx, st, MIRT_MODE_NO_SELF, ctx->shb.o, ctx->shb.d, ctx->shb.ids, ctx->shb.lim,
+                                        bound, ctx->shb.stride, ctx->shb.vis, n_sh, ctx->d_wq2 + depth);
+            if (rcv != MIRT_OK) return rcv;
+            hipLaunchKernelGGL(k_connect, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->shb, n_sh, bound, ctx->d_L,
+                               (uint32_t)ctx->pb_cap);
+        } else if (ctx->has_media)
             hipLaunchKernelGGL(k_shade<true>, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in,
                                bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, depth, prm->max_depth);
         else
@@ -932,11 +1051,16 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
     HIPCHK(ctx, hipStreamSynchronize(st));
     *n_rays += P;
     for (uint32_t k = 1; k < depths_run + 1 && k <= prm->max_depth; k++) *n_rays += ctx->h_cnt[k];
+    if (nee && n_shadow) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, ctx->d_ns, depths_run * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        for (uint32_t k = 0; k < depths_run; k++) *n_shadow += ctx->h_cnt[k];
+    }
     return MIRT_OK;
 }
 
 static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* rgb_sum_dev, Capture* cap,
-                         MirtRenderStats* stats) {
+                         MirtRenderStats* stats, bool nee = false) {
     if (!ctx) return MIRT_E_INVALID;
     if (!ctx->has_scene) return fail(ctx, MIRT_E_NO_SCENE, "render: no scene uploaded");
     if (!prm) return fail(ctx, MIRT_E_INVALID, "render: params is NULL");
@@ -956,8 +1080,17 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     if (S == 0) S = (uint32_t)std::max<uint64_t>(1, (1ull << 27) / wh);
     S = std::min<uint32_t>(S, std::max<uint32_t>(prm->spp_count, 1));
     if (wh * S > (1ull << 30)) return fail(ctx, MIRT_E_LIMIT, "render: more than 2^30 paths per wavefront");
+    if (nee && ctx->has_media)
+        return fail(ctx, MIRT_E_INVALID, "render_pttest: scenes that hold a medium (MIRT_OBJ_VPM) are not supported "
+                                         "by the light-connection integrator");
+    if (nee) S = std::min<uint32_t>(S, (uint32_t)std::max<uint64_t>(1, (1ull << 26) / wh));
     rc = ensure_paths(ctx, (size_t)(wh * S));
     if (rc != MIRT_OK) return rc;
+    if (nee) {
+        rc = ensure_shadow(ctx, (size_t)(wh * S));
+        if (rc != MIRT_OK) return rc;
+    }
+    uint64_t n_shadow = 0;
     hipEvent_t t0 = get_event(ctx, 0), t1 = get_event(ctx, 1);
     if (!t0 || !t1) return fail(ctx, MIRT_E_HIP, "hipEventCreate failed");
     size_t ev_used = 2;
@@ -965,7 +1098,7 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     HIPCHK(ctx, hipEventRecord(t0, ctx->stream));
     for (uint32_t done = 0; done < prm->spp_count; done += S) {
         uint32_t s = std::min(S, prm->spp_count - done);
-        rc = run_wavefront(ctx, cam, prm, prm->spp_begin + done, s, rgb_sum_dev, cap, &n_rays, &ev_used);
+        rc = run_wavefront(ctx, cam, prm, prm->spp_begin + done, s, rgb_sum_dev, cap, &n_rays, &ev_used, nee, &n_shadow);
         if (rc != MIRT_OK) return rc;
         if (ev_used > 4096) {  // fold the event pool so long renders do not grow it without bound
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -991,6 +1124,7 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
             stats->intersect_ms += m2;
         }
         stats->n_rays = n_rays;
+        stats->n_shadow_rays = n_shadow;
         stats->n_samples = wh * prm->spp_count;
     }
     return MIRT_OK;
@@ -1038,6 +1172,36 @@ int mirt_render_pt(MirtContext* ctx, const MirtRenderParams* params, float* rgb_
     HIPCHK(ctx, hipMalloc(&d_rgb, bytes));
     hipError_t e = hipMemsetAsync(d_rgb, 0, bytes, ctx->stream);
     int rc = e == hipSuccess ? render_common(ctx, params, d_rgb, nullptr, stats)
+                             : fail(ctx, MIRT_E_HIP, hipGetErrorString(e));
+    if (rc == MIRT_OK) {
+        e = hipMemcpy(rgb_sum, d_rgb, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, MIRT_E_HIP, hipGetErrorString(e));
+    }
+    hipFree(d_rgb);
+    return rc;
+}
+
+int mirt_render_pttest_dev(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
+                           MirtRenderStats* stats) {
+    if (stats) *stats = MirtRenderStats{};
+    if (ctx && !rgb_sum) return fail(ctx, MIRT_E_INVALID, "render_pttest: rgb_sum is NULL");
+    return render_common(ctx, params, rgb_sum, nullptr, stats, true);
+}
+
+int mirt_render_pttest(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
+                       MirtRenderStats* stats) {
+    if (stats) *stats = MirtRenderStats{};
+    if (!ctx) return MIRT_E_INVALID;
+    if (!rgb_sum || !params) return fail(ctx, MIRT_E_INVALID, "render_pttest: NULL argument");
+    if (!ctx->has_scene) return fail(ctx, MIRT_E_NO_SCENE, "render_pttest: no scene uploaded");
+    if (params->camera.width <= 0 || params->camera.height <= 0)
+        return fail(ctx, MIRT_E_INVALID, "camera: width/height must be positive");
+    size_t bytes = (size_t)params->camera.width * params->camera.height * 3 * sizeof(float);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    float* d_rgb = nullptr;
+    HIPCHK(ctx, hipMalloc(&d_rgb, bytes));
+    hipError_t e = hipMemsetAsync(d_rgb, 0, bytes, ctx->stream);
+    int rc = e == hipSuccess ? render_common(ctx, params, d_rgb, nullptr, stats, true)
                              : fail(ctx, MIRT_E_HIP, hipGetErrorString(e));
     if (rc == MIRT_OK) {
         e = hipMemcpy(rgb_sum, d_rgb, bytes, hipMemcpyDeviceToHost);

@@ -63,7 +63,18 @@ struct DevObject {
     float sigma_s[3];  // homogeneous medium (SceneVPMObject.h:13-14): ds, dt = ds + da, HG g
     float sigma_t[3];
     float g;
-    float pad2;
+    float emit_pdf_a;  // emissive objects: weight / totalArea of the emission sampler (SceneObject.cpp:11-21,
+                       // Scene.cpp:19-33), the area density PathTracerTest.cpp:38 uses for MIS
+};
+// emission sampler tables (Scene::preprocessEmissionSampler, Scene.cpp:193-204): one record per
+// emissive object in scene order; its triangles' running areas live in DevScene.light_area / the
+// slots of those triangles in DevScene.light_slot at [first, first + count)
+struct DevLight {
+    float weight_sum;   // running sum of the un-normalised weights up to and including this object
+    float total_area;   // SceneObject::totalArea
+    float origin_prob;  // weight / totalArea after normalizeEmissionWeight (SceneObject.cpp:156)
+    int first, count, object;
+    int pad[2];
 };
 // root record of one volumetric object's own tree (Scene::objKDTrees, Scene.cpp:287-320):
 // lo.w = bits(link), hi.w = bits(flat), like a PairRec child
@@ -82,6 +93,11 @@ struct DevScene {
     int n_vols;
     int n_nodes, n_tris, n_objects, depth;
     float bound[3];       // max |coordinate| of the root box per axis
+    const DevLight* lights;    // emission sampler (PathTracerTest's light connections)
+    const float* light_area;   // running triangle areas per light object (SceneObject::areaValues)
+    const int* light_slot;     // slot of each light triangle
+    int n_lights;
+    float light_total_weight;  // SurfaceSampler::totalWeight
     int fast_ok;          // every node bound is 0 or in [2^-36, 2^60): the slab classifier may be used
 };
 

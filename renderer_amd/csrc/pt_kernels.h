@@ -22,6 +22,21 @@ struct PathBuf {
     uint32_t* ctr;   // [stride]    RNG draw counter
     int* ids;        // [stride]    MIRT_PACK_IDS(contact, inside) of the ray
     uint32_t* pid;   // [stride]    original path index = sample_local * W*H + pixel
+    float* lpw;      // [stride]    PathTracerTest only: directionProb of the previous vertex, or < 0 when
+                     //             that vertex was DEFINITE / there is none (lastSpecular, PathTracerTest.cpp:29-30)
+    uint32_t stride;
+};
+
+// Shadow rays of one bounce of PathTracerTest (colorByConnectingLights, PathTracerTest.cpp:85-135):
+// what the visibility launch reads (o, d, ids, lim) and what k_connect adds to L when unoccluded.
+struct ShadowBuf {
+    float* o;       // [3][stride]
+    float* d;       // [3][stride]
+    int* ids;       // [stride] MIRT_PACK_IDS(contact, inside) of the vertex
+    float* lim;     // [stride] distance to the light sample
+    float* c;       // [3][stride] throughput * contribution * MIS weight
+    uint32_t* pid;  // [stride]
+    unsigned char* vis;  // [stride] written by the visibility launch
     uint32_t stride;
 };
 
@@ -89,6 +104,10 @@ k_generate(DevCamera cam, uint32_t n, uint32_t spp_begin, uint32_t seed, float* 
         // contact object (Camera.cpp:25, Ray.cpp:71-78)
         float c0 = fabsf(dot3(cam.front, dir));
         c0 = c0 > 1e-6f ? c0 : 1e-6f;
+        if (fill_state == 2) {  // PathTracerTest.cpp:26-30: throughput 1, lastSpecular, the loop starts at vertex 1
+            c0 = 1.f;
+            pb.lpw[i] = -1.f;
+        }
         store3(pb.thr, pb.stride, i, mk3(c0, c0, c0));
         pb.key[i] = key;
         pb.ctr[i] = ctr;
@@ -256,6 +275,8 @@ struct Scatter {
     int contact, inside;  // of the outgoing ray
     bool cos_term;     // the new vertex has a cosine term against `nn` (Ray.cpp:71-78)
     bool emitted;      // the path ended on an emitter: score it
+    bool random;       // directionSampleType == Ray::RANDOM (Ray.h:46 default; DEFINITE for the diffuse
+                       // pass-through, DiffuseMaterial.cpp:42, and every refractive outcome, RefractiveMaterial.cpp:31)
     f3 nn;             // contact normal (when cos_term)
 };
 
@@ -326,6 +347,7 @@ __device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const Dev
     r.inside = inside;
     r.cos_term = true;
     r.emitted = false;
+    r.random = true;
     r.nn = nn;
     const f3 col = mk3(ob.color[0], ob.color[1], ob.color[2]);
     if (ob.type == MIRT_OBJ_EMISSIVE) {
@@ -337,6 +359,7 @@ __device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const Dev
         if (dot3(d, nn) > 0.f) {  // DiffuseMaterial.cpp:35-44: back side passes through
             r.nd = d;
             r.color = mk3(1, 1, 1);
+            r.random = false;
         } else {
             Frame lf = frame_from_normal(nn);
             float dx = rng_float(key, ctr), dy = rng_float(key, ctr);
@@ -368,6 +391,7 @@ __device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const Dev
             }
         }
     } else if (ob.type == MIRT_OBJ_REFRACTIVE) {
+        r.random = false;
         if (ob.ior < 0.f) {  // mirror
             f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
             r.nd = refl;
@@ -391,6 +415,90 @@ __device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const Dev
     return r;
 }
 
+
+// SurfaceSampler::genSample / SceneObject::emit: first index whose running sum is >= rnd
+// (std::lower_bound, Scene.cpp:94, SceneObject.cpp:152), clamped to the last
+__device__ __forceinline__ int lower_bound_clamped(const float* v, int n, float rnd) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v[mid] < rnd) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo >= n ? n - 1 : lo;
+}
+__device__ __forceinline__ uint32_t connection_key(uint32_t key) { return lowbias32(key ^ 0x5bd1e995U); }
+
+// colorByConnectingLights (PathTracerTest.cpp:85-135) up to, but not including, the visibility test:
+// samples the emission sampler (Scene.cpp:91-98, SceneObject.cpp:137-160, SimpleShape.cpp:28-42) and
+// returns contribution * MIS weight together with the shadow ray (direction, length). `hob`: the
+// vertex's contact object; `d`: direction of the ray that arrived at the vertex (lastRay.direction).
+// Six draws of the connection stream at 6 * vertexIndex: object, triangle, two for the point, two
+// for the emitted direction that the connection overwrites. Returns false when nothing can arrive.
+__device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObject& hob, f3 nn, f3 pos, f3 d,
+                                              uint32_t key, uint32_t vertex, f3& out_dir, float& out_dist, f3& contrib) {
+    if (sc.n_lights <= 0) return false;
+    const uint32_t ck = connection_key(key);
+    uint32_t cc = 6u * vertex;
+    float rnd = rng_float(ck, cc) * sc.light_total_weight;
+    int li = 0;
+    {  // few lights: running sums read through the records
+        int lo = 0, hi = sc.n_lights;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sc.lights[mid].weight_sum < rnd) lo = mid + 1;
+            else hi = mid;
+        }
+        li = lo >= sc.n_lights ? sc.n_lights - 1 : lo;
+    }
+    const DevLight Lg = sc.lights[li];
+    rnd = rng_float(ck, cc) * Lg.total_area;
+    const int ti = lower_bound_clamped(sc.light_area + Lg.first, Lg.count, rnd);
+    const int lslot = sc.light_slot[Lg.first + ti];
+    const TriRec LT = sc.tris[lslot];
+    const float u1 = rng_float(ck, cc), u2 = rng_float(ck, cc);
+    const float su1 = sqrtf(u1);
+    const float u = 1.f - su1, v = u2 * su1;
+    const f3 y = (mk3(LT.a.x, LT.a.y, LT.a.z) * u + mk3(LT.b.x, LT.b.y, LT.b.z) * v) +
+                 mk3(LT.c.x, LT.c.y, LT.c.z) * ((1.f - u) - v);
+    const DevObject lob = sc.objects[Lg.object];
+    f3 ldir = pos - y;  // lightRay.direction = ray.origin - lightRay.origin
+    const float dist = len3(ldir);
+    const float dist2 = dist * dist;
+    ldir = normalize3(ldir);
+    const f3 odir = neg(ldir);
+    // lastRay.getBSDF(outRay): DiffuseMaterial.cpp:94-101, GlossyMaterial.cpp:69-79 (times max colour)
+    const f3 col = mk3(hob.color[0], hob.color[1], hob.color[2]);
+    f3 bsdf = mk3(0, 0, 0);
+    float pdf = 0.f;
+    const bool sides = dot3(nn, d) <= 0.f && dot3(nn, odir) >= 0.f;
+    if (hob.type == MIRT_OBJ_DIFFUSE) {
+        if (sides) bsdf = div3(col, 3.14159265358979f);
+        pdf = max3f(col) * cos_pdf(nn, odir, 1.f);  // DiffuseMaterial.cpp:78-86
+    } else if (hob.type == MIRT_OBJ_GLOSSY) {
+        const f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
+        if (sides) {
+            const float rd = dot3(refl, odir);
+            if (rd > 0.f) bsdf = (col * powf(rd, hob.coeff)) * max3f(col);
+        }
+        pdf = cos_pdf(refl, odir, hob.coeff);  // GlossyMaterial.cpp:58-67
+    }
+    if (lum_y(bsdf) < 1e-7f) return false;
+    const VnRec LV = sc.vns[lslot];
+    const f3 nl = world_normal(LT, LV, __float_as_int(LV.n2.w) != 0, y);
+    const float cos_at_light = fminf(fmaxf(0.f, fabsf(dot3(nl, ldir))), 1.f);
+    if (cos_at_light < 1e-6f) return false;
+    const float cos_to_light = fminf(fmaxf(0.f, fabsf(dot3(nn, odir))), 1.f);
+    const float dir_pdf_w = Lg.origin_prob * dist2 / cos_at_light;
+    const float mis = dir_pdf_w / (dir_pdf_w + pdf);
+    const f3 lcol = mk3(lob.color[0], lob.color[1], lob.color[2]);
+    const f3 tmp = div3(((lcol * cos_at_light) * bsdf) * cos_to_light, Lg.origin_prob * dist2);
+    contrib = tmp * mis;
+    out_dir = odir;
+    out_dist = dist;
+    return true;
+}
+
 // One bounce for every live path: score emitter hits, scatter, Russian roulette, write the next ray
 // of each surviving path to `out` at a compacted position (wave ballot + block prefix + one atomic
 // per block). Results do not depend on the order of `out` (RNG and radiance slots are keyed by pid).
@@ -398,13 +506,20 @@ __device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const Dev
 // is inside one is the medium's (MCRenderer.cpp:167-170), camera rays look up their inside object
 // (Camera.cpp:35), and the private stack of trace_object costs scratch memory; scenes without media
 // run the VOL = false instantiation, which has none of it.
-template <bool VOL>
+// NEE: PathTracerTest (PathTracerTest.cpp:20-78) instead of PathTracer: the throughput is the
+// reference's `throughput` there (no originProb, no camera cosine, no vignetting compensation), an
+// emitter hit is weighted against the light connection that could have found it, and every RANDOM
+// vertex writes one shadow ray + its pending contribution to `sh` (compacted like the paths); the
+// visibility launch and k_connect finish it. Scenes without media only (checked on the host).
+template <bool VOL, bool NEE = false>
 __global__ void __launch_bounds__(256)
 k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_in, uint32_t n_max,
         PathBuf out, uint32_t* __restrict__ n_out, float* __restrict__ L, uint32_t L_stride,
-        uint32_t depth, uint32_t max_depth) {
+        uint32_t depth, uint32_t max_depth, ShadowBuf sh = ShadowBuf{}, uint32_t* __restrict__ n_sh = nullptr) {
     __shared__ uint32_t s_wcnt[4];
     __shared__ uint32_t s_base;
+    __shared__ uint32_t s_wcnt2[4];
+    __shared__ uint32_t s_base2;
     const uint32_t n = n_in ? min(*n_in, n_max) : n_max;
     if (blockIdx.x * blockDim.x >= n) return;  // the grid is sized for n_max; whole block, before any barrier
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -413,6 +528,10 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
     f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0), thr = mk3(0, 0, 0);
     uint32_t key = 0, ctr = 0, pid = 0;
     int nids = 0;
+    bool shadow = false;  // NEE: this lane emits a shadow ray
+    f3 sh_o = mk3(0, 0, 0), sh_d = mk3(0, 0, 0), sh_c = mk3(0, 0, 0);
+    float sh_lim = 0.f, lpw = -1.f;
+    int sh_ids = 0;
 
     if (i < n) {
         const int slot = in.slot[i];
@@ -517,6 +636,59 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                 sr = surface_scatter<VOL>(sc, ob, hobj, nn, pos, d, inside, key, ctr);
             }
 
+            if (NEE) {
+                // vertex i = depth + 1 of the eye path, reached from x_{i-1} = o along d
+                const bool same = depth >= 1 && sr.pos.x == o.x && sr.pos.y == o.y && sr.pos.z == o.z;  // PathTracerTest.cpp:65
+                // the vertex is in the path when it ended there or the depth cap lets it continue
+                // (MCRenderer.cpp:181-191: the zero-direction test comes before the cap)
+                const bool counted = len3(sr.nd) < 0.5f || depth + 1 <= max_depth;
+                if (!same && counted) {
+                    if (sr.emitted) {  // PathTracerTest.cpp:34-57 (the colour whatever the side, getColor())
+                        float mis = 1.f;
+                        const float last = in.lpw[i];
+                        if (depth >= 1 && last >= 0.f) {
+                            const float cosine = dot3(nn, neg(d));
+                            const float dist = len3(sr.pos - o);
+                            const float dir_pdf_w = ob.emit_pdf_a * dist * dist / fabsf(cosine);
+                            mis = last / (last + dir_pdf_w);
+                        }
+                        const f3 add = (thr * mk3(ob.color[0], ob.color[1], ob.color[2])) * mis;
+                        L[pid] += add.x;
+                        L[L_stride + pid] += add.y;
+                        L[2 * L_stride + pid] += add.z;
+                    } else {
+                        if (sr.random) {  // PathTracerTest.cpp:59-63
+                            f3 cdir, contrib;
+                            float cdist;
+                            if (connect_light(sc, ob, nn, sr.pos, d, key, depth + 1, cdir, cdist, contrib)) {
+                                shadow = true;
+                                sh_o = sr.pos;
+                                sh_d = cdir;
+                                sh_lim = cdist;
+                                sh_c = thr * contrib;
+                                sh_ids = MIRT_PACK_IDS(sr.contact, sr.inside);
+                            }
+                        }
+                        if (len3(sr.nd) >= 0.5f) {  // PathTracerTest.cpp:68-76
+                            lpw = sr.random ? sr.dirProb : -1.f;
+                            float ct = fabsf(dot3(sr.nn, sr.nd));
+                            ct = ct > 1e-6f ? ct : 1e-6f;
+                            thr = thr * div3(sr.color * ct, sr.dirProb);
+                            if (inside >= 0) {
+                                const DevObject io = sc.objects[inside];
+                                if (io.type == MIRT_OBJ_REFRACTIVE) {
+                                    const float dist = fmaxf(len3(sr.pos - o), 1e-5f);
+                                    thr = thr * mk3(powf(io.decay[0], dist), powf(io.decay[1], dist), powf(io.decay[2], dist));
+                                }
+                            }
+                            alive = depth + 1 <= max_depth;
+                            no = sr.pos;
+                            nd = sr.nd;
+                            nids = MIRT_PACK_IDS(sr.contact, sr.inside);
+                        }
+                    }
+                }
+            } else {
             // decay along the finished segment (Ray.cpp:66-69): RefractiveMaterial.h:15 or the
             // medium's transmittance (SceneVPMObject.cpp:235-237), over the distance between vertices
             if (inside >= 0) {
@@ -548,6 +720,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                 no = sr.pos;
                 nids = MIRT_PACK_IDS(sr.contact, sr.inside);
             }
+            }  // !NEE
         }
     }
 
@@ -556,12 +729,29 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) s_wcnt[w] = __popcll(m);
+    const unsigned long long m2 = NEE ? __ballot(shadow) : 0ull;
+    if (NEE && lane == 0) s_wcnt2[w] = __popcll(m2);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
         s_base = tot ? atomicAdd(n_out, tot) : 0u;
+        if (NEE) {
+            uint32_t tot2 = s_wcnt2[0] + s_wcnt2[1] + s_wcnt2[2] + s_wcnt2[3];
+            s_base2 = tot2 ? atomicAdd(n_sh, tot2) : 0u;
+        }
     }
     __syncthreads();
+    if (NEE && shadow) {
+        uint32_t wb = 0;
+        for (uint32_t k = 0; k < w; k++) wb += s_wcnt2[k];
+        const uint32_t j = s_base2 + wb + (uint32_t)__popcll(m2 & ((1ull << lane) - 1ull));
+        store3(sh.o, sh.stride, j, sh_o);
+        store3(sh.d, sh.stride, j, sh_d);
+        store3(sh.c, sh.stride, j, sh_c);
+        sh.lim[j] = sh_lim;
+        sh.ids[j] = sh_ids;
+        sh.pid[j] = pid;
+    }
     if (alive) {
         uint32_t wb = 0;
         for (uint32_t k = 0; k < w; k++) wb += s_wcnt[k];
@@ -573,7 +763,22 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
         out.ctr[j] = ctr;
         out.ids[j] = nids;
         out.pid[j] = pid;
+        if (NEE) out.lpw[j] = lpw;
     }
+}
+
+// Adds the pending contribution of every unoccluded light connection to its path's radiance
+// (PathTracerTest.cpp:62 after MCRenderer::testVisibility, PathTracerTest.cpp:97-98). One shadow ray
+// per path and bounce, so no two lanes touch the same L entry.
+__global__ void __launch_bounds__(256)
+k_connect(ShadowBuf sh, const uint32_t* __restrict__ n_ptr, uint32_t n_max, float* __restrict__ L, uint32_t L_stride) {
+    const uint32_t n = min(*n_ptr, n_max);
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || !sh.vis[j]) return;
+    const uint32_t pid = sh.pid[j];
+    L[pid] += sh.c[j];
+    L[L_stride + pid] += sh.c[sh.stride + j];
+    L[2 * L_stride + pid] += sh.c[2 * sh.stride + j];
 }
 
 // rgb_sum[p] += sum over the launch's samples of L, in sample order (deterministic).

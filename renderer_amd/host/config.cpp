@@ -206,14 +206,15 @@ void ConfigManager::load(const std::string& configFilePath) {
         typeName = r->first_node("type")->value();
         opts = r;
     }
-    if (typeName == "PathTracer" || typeName == "PT" || typeName == "PTHIP") {
-        PathTracerHIP* pt = new PathTracerHIP(renderer);
+    const bool isTest = typeName == "PTtest" || typeName == "PathTracerTest";  // ConfigManager.cpp:285-288
+    if (typeName == "PathTracer" || typeName == "PT" || typeName == "PTHIP" || isTest) {
+        PathTracerHIP* pt = isTest ? new PathTracerTestHIP(renderer) : new PathTracerHIP(renderer);
         if (opts->first_node("spp")) pt->spp = (unsigned)atoi(opts->first_node("spp")->value());
         if (opts->first_node("seed")) pt->seed = (unsigned)atoi(opts->first_node("seed")->value());
         renderer->mcRenderer = pt;
     } else {
         throw std::runtime_error("ConfigManager: renderer type '" + typeName +
-                                 "' is outside this build (PathTracer / PT / PTHIP only)");
+                                 "' is outside this build (PathTracer / PT / PTHIP / PTtest only)");
     }
     if (opts->first_node("maxDepth")) renderer->mcRenderer->setMaxDepth(atoi(opts->first_node("maxDepth")->value()));
     if (nodeConfig->first_node("savePath")) renderer->mcRenderer->setSavePath(nodeConfig->first_node("savePath")->value());
@@ -287,7 +288,7 @@ std::vector<vec3f> PathTracerHIP::renderPixels(const Camera& camera) {
     p.spp_per_launch = sppPerLaunch;
     const size_t npix = (size_t)camera.width * camera.height;
     std::vector<float> sum(3 * npix);
-    if (mirt_render_pt(ctx, &p, sum.data(), &lastStats) != MIRT_OK)
+    if (launch(ctx, &p, sum.data(), &lastStats) != MIRT_OK)
         throw std::runtime_error(std::string("PathTracerHIP::renderPixels: ") + mirt_last_error(ctx));
     std::vector<vec3f> pixelColors(npix);
     const float inv = spp ? 1.f / float(spp) : 0.f;
@@ -295,6 +296,14 @@ std::vector<vec3f> PathTracerHIP::renderPixels(const Camera& camera) {
         pixelColors[i] = vec3f(sum[3 * i] * inv, sum[3 * i + 1] * inv, sum[3 * i + 2] * inv);
     if (!savePath.empty()) saveImagePFM(savePath, pixelColors, camera.width, camera.height);
     return pixelColors;
+}
+
+int PathTracerHIP::launch(MirtContext* ctx, const MirtRenderParams* p, float* rgb_sum, MirtRenderStats* stats) {
+    return mirt_render_pt(ctx, p, rgb_sum, stats);
+}
+
+int PathTracerTestHIP::launch(MirtContext* ctx, const MirtRenderParams* p, float* rgb_sum, MirtRenderStats* stats) {
+    return mirt_render_pttest(ctx, p, rgb_sum, stats);
 }
 
 // ---- Renderer ---------------------------------------------------------------------------------------

@@ -212,6 +212,21 @@ public:
     MirtRenderStats lastStats{};
     explicit PathTracerHIP(Renderer* r) : MCRenderer(r) {}
     std::vector<vec3f> renderPixels(const Camera& camera) override;
+
+protected:
+    // the device entry point this integrator runs on (mirt_render_pt)
+    virtual int launch(MirtContext* ctx, const MirtRenderParams* p, float* rgb_sum, MirtRenderStats* stats);
+};
+
+// PathTracerTest.h / PathTracerTest.cpp:7-135 ("PTtest", ConfigManager.cpp:285-288): the reference's
+// cross-check integrator, path tracing + one light connection per RANDOM vertex with MIS
+// (useConnection is always on there, PathTracerTest.h:16). Runs on mirt_render_pttest.
+class PathTracerTestHIP : public PathTracerHIP {
+public:
+    explicit PathTracerTestHIP(Renderer* r) : PathTracerHIP(r) {}
+
+protected:
+    int launch(MirtContext* ctx, const MirtRenderParams* p, float* rgb_sum, MirtRenderStats* stats) override;
 };
 
 // ConfigManager.h:20-70

@@ -9,6 +9,7 @@ spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 cfg = sys.argv[3] if len(sys.argv) > 3 else "Config_Glossy1024.xml"
 spl = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+mode = sys.argv[5] if len(sys.argv) > 5 else "pt"  # pt | pttest
 scene = ra.HostScene.load_config(os.path.join(ROOT, "Data", cfg))
 cam = scene.camera(); dev = ra.Device(device=0); dev.upload(scene.describe())
 wh = cam.width * cam.height
@@ -17,12 +18,12 @@ best = None
 for r in range(reps + 1):
     acc.zero_(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    st = dev.render_pt_dev(cam, acc.data_ptr(), spp, seed=1, spp_per_launch=spl)
+    st = (dev.render_pttest_dev if mode == "pttest" else dev.render_pt_dev)(cam, acc.data_ptr(), spp, seed=1, spp_per_launch=spl)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if r and (best is None or dt < best[0]):
         best = (dt, st)
 dt, st = best
-print("%-32s %s spp %d spl %d: %.2f ms wall, gpu %.2f ms, intersect %.2f ms, %.1f Msamples/s, %.1f Mrays/s, mean %.5f" % (
+print("%-32s %s spp %d spl %d: %.2f ms wall, gpu %.2f ms, intersect %.2f ms, %.1f Msamples/s, %.1f Mrays/s (+%.1f Mshadow/s), mean %.5f [%s]" % (
     os.path.basename(os.environ.get("MIRT_LIB", "libmirt.so")), cfg, spp, spl, dt * 1e3, st.gpu_ms, st.intersect_ms,
-    wh * spp / dt / 1e6, st.n_rays / dt / 1e6, float(acc.mean().item()) / spp), flush=True)
+    wh * spp / dt / 1e6, st.n_rays / dt / 1e6, st.n_shadow_rays / dt / 1e6, float(acc.mean().item()) / spp, mode), flush=True)

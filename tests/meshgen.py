@@ -119,6 +119,30 @@ def cornell_with_meshes(level, seed=7, smooth=True):
                 objects=np.array(objects, ra.OBJECT_DTYPE))
 
 
+def _assemble(parts):
+    verts, tris, tri_obj, tri_vn, objects = [], [], [], [], []
+    off = 0
+    for oi, (v, f, vn, ob) in enumerate(parts):
+        verts.append(v)
+        tris.append(f + off)
+        tri_obj.append(np.full(len(f), oi, np.int32))
+        tri_vn.append(vn[f].reshape(len(f), 9))
+        objects.append(ob.copy())
+        off += len(v)
+    return dict(verts=np.concatenate(verts).astype(np.float32), tris=np.concatenate(tris).astype(np.uint32),
+                tri_obj=np.concatenate(tri_obj), tri_vn=np.concatenate(tri_vn).astype(np.float32),
+                objects=np.array(objects, ra.OBJECT_DTYPE))
+
+
+def floor_and_light(albedo=0.6, emission=5.0):
+    """a large diffuse floor at y = -1 under a unit-square emitter at y = 1 facing down; nothing else"""
+    parts = [_quad((-0.5, 1, -0.5), (0.5, 1, -0.5), (0.5, 1, 0.5), (-0.5, 1, 0.5), (0, -1, 0)) +
+             (_obj(ra.OBJ_EMISSIVE, (emission,) * 3),),
+             _quad((-20, -1, -20), (20, -1, -20), (20, -1, 20), (-20, -1, 20), (0, 1, 0)) +
+             (_obj(ra.OBJ_DIFFUSE, (albedo,) * 3),)]
+    return _assemble(parts)
+
+
 def mesh_scene(level, seed=7, smooth=True):
     m = cornell_with_meshes(level, seed, smooth)
     return ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"], m["objects"],

@@ -53,6 +53,12 @@ def lib():
         L.orc_hemi_cos.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.orc_render_pt.argtypes = [C.c_void_p, C.POINTER(OrcCamera), C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        L.orc_render_pttest.argtypes = [C.c_void_p, C.POINTER(OrcCamera), C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
+        L.orc_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_int, C.c_void_p, C.c_int]
+        for f in ("orc_local_frame", "orc_to_world", "orc_face_normal", "orc_interp_normal", "orc_normalize"):
+            getattr(L, f).restype = None
         L.orc_trace_path.restype = C.c_int32
         L.orc_trace_path.argtypes = [C.c_void_p, C.POINTER(OrcCamera), C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p]
@@ -113,8 +119,6 @@ class OracleScene:
         a = None if aux is None else np.ascontiguousarray(aux, np.int32)
         m = np.ascontiguousarray(max_dist, np.float32)
         vis = np.empty(o.shape[1], np.uint8)
-        lib().orc_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                         C.c_int, C.c_void_p, C.c_int]
         lib().orc_visibility(self.h, _p(o), _p(d), _p(a), _p(m), o.shape[1], mode, _p(vis), threads)
         return vis
 
@@ -155,6 +159,17 @@ class OracleScene:
         lib().orc_render_pt(self.h, C.byref(oc), spp_begin, spp_count, max_depth, seed, _p(img), C.byref(nr),
                             threads)
         return img, nr.value
+
+    def render_pttest(self, cam, spp_count, spp_begin=0, max_depth=20, seed=1, threads=8):
+        """PathTracerTest: returns (sum image, closest-hit rays, shadow rays)"""
+        oc = camera_from(cam)
+        img = np.zeros((oc.height, oc.width, 3), np.float32)
+        nr, ns = C.c_uint64(), C.c_uint64()
+        rc = lib().orc_render_pttest(self.h, C.byref(oc), spp_begin, spp_count, max_depth, seed, _p(img), C.byref(nr),
+                                     C.byref(ns), threads)
+        if rc != 0:
+            raise RuntimeError("orc_render_pttest: scenes with a medium are not restated")
+        return img, nr.value, ns.value
 
     def trace_path(self, cam, pixel, sample, max_depth=20, seed=1, cap=64):
         oc = camera_from(cam)

@@ -84,6 +84,14 @@ def test_describe_is_consistent(cornell, ra):
     assert d.n_nodes == cornell.n_nodes
 
 
+def test_pttest_renderer_type_loads(ra):
+    """<type>PTtest</type> (ConfigManager.cpp:285-288) selects the light-connection integrator"""
+    s = ra.HostScene.load_config(os.path.join(DATA, "Config_Glossy128_PTtest.xml"))
+    assert s.render_cfg() == dict(max_depth=20, spp=64, seed=1)
+    assert s.n_tris == 1932
+    s.close()
+
+
 def test_config_errors(ra, tmp_path):
     with pytest.raises(ra.MirtError, match="cannot open"):
         ra.HostScene.load_config(str(tmp_path / "missing.xml"))

@@ -320,3 +320,48 @@ def test_medium_known_answers(orc, ra):
     assert 50 * np.exp(-0.5 * 2.0) * 0.97 < got < 50.0, got
     S.close()
     s.close()
+
+
+def test_pttest_converges_to_path_tracer(cornell_oracle, cornell):
+    """PathTracerTest is the reference's cross-check of PathTracer: same expectation, less noise.
+    64x64 view of the Cornell scene; block means compared."""
+    import renderer_amd as ra
+
+    cam = ra.make_camera(64, 64, 44)
+    a, _ = cornell_oracle.render(cam, 192, seed=11, threads=8)
+    b, nr, ns = cornell_oracle.render_pttest(cam, 48, seed=12, threads=8)
+    a, b = np.clip(a / 192, 0, 1), np.clip(b / 48, 0, 1)
+    assert ns > 0 and nr > 0
+    assert np.abs(a.mean((0, 1)) - b.mean((0, 1))).max() < 0.02
+    blk = lambda x: x.reshape(8, 8, 8, 8, 3).mean((1, 3))
+    assert np.abs(blk(a) - blk(b)).max() < 0.15
+
+
+def test_pttest_direct_light_known_answer(orc, ra):
+    """A diffuse floor under a square emitter, nothing else, maxDepth 1: the only light a floor pixel
+    receives is the connection at its first vertex plus (MIS-weighted) emitter hits at depth 2, which
+    the cap removes... so with maxDepth 1 the floor shows exactly the direct light E * rho/pi * G,
+    integrated over the emitter: compare with a numerical quadrature."""
+    import meshgen
+
+    m = meshgen.floor_and_light(albedo=0.6, emission=5.0)
+    s = ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"], m["objects"], m["tri_vn"])
+    S = orc.OracleScene(s.raw())
+    cam = ra.make_camera(16, 16, 16, position=(0, 0.5, 2.5), focus=(0, -1, 0))
+    img, _, _ = S.render_pttest(cam, 4000, max_depth=1, seed=3, threads=8)
+    img /= 4000
+    # centre pixel looks at the floor point where the view axis meets y = -1
+    t = (-1 - 0.5) / (-1.5 / np.linalg.norm((0, -1.5, -2.5)))
+    x = np.array([0, 0.5, 2.5]) + t * np.array([0, -1.5, -2.5]) / np.linalg.norm((0, -1.5, -2.5))
+    # quadrature over the emitter square (y = 1, |x|,|z| <= 0.5, facing down)
+    g = (np.arange(200) + 0.5) / 200 - 0.5
+    yx, yz = np.meshgrid(g, g)
+    dvec = np.stack([yx - x[0], np.full_like(yx, 1 - x[1]), yz - x[2]], -1)
+    r2 = (dvec ** 2).sum(-1)
+    cos_f = dvec[..., 1] / np.sqrt(r2)
+    cos_l = dvec[..., 1] / np.sqrt(r2)
+    expect = 5.0 * 0.6 / np.pi * (cos_f * cos_l / r2).mean() * 1.0
+    got = img[7:9, 7:9].mean()
+    assert abs(got - expect) / expect < 0.05, (got, expect)
+    S.close()
+    s.close()
