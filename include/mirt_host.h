@@ -46,6 +46,13 @@ int mirth_upload(MirthScene* s, MirtContext** ctx_out);
 /* Renderer::render (Renderer.cpp:46-50) through PathTracerHIP::renderPixels: mean image
  * rgb[W*H*3]; spp/seed 0 = take the config's. */
 int mirth_render(MirthScene* s, uint32_t spp, uint32_t seed, float* rgb_mean, MirtRenderStats* stats);
+/* The same with the reference's progressive output (PathTracer.cpp:47-55, MCRenderer::showCurrentResult,
+ * MCRenderer.cpp:396-437): output_iter > 0 dumps the running mean to savePath and to
+ * "<savePath stem>_iter_<s>_time_<seconds>.pfm" after every pass s with s % output_iter == 0 (the series
+ * compare.cpp:167-251 reads). resume_from / save_state (may be NULL): accumulator files (radiance sums +
+ * pass count) so that a render can be continued later; `spp` is the TOTAL number of passes wanted. */
+int mirth_render_progressive(MirthScene* s, uint32_t spp, uint32_t seed, int32_t output_iter, const char* resume_from,
+                             const char* save_state, float* rgb_mean, MirtRenderStats* stats);
 /* Scene::fillIntersectObject (Scene.cpp:431-453) on AoS rays: o[n*3], d[n*3], contact/inside
  * object ids (-1 = NULL) -> dist[n], global tid[n] (-1 = miss), objID[n], local triangle id[n] */
 int mirth_fill_intersect(MirthScene* s, size_t n, const float* o, const float* d, const int32_t* contact,

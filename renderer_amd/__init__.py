@@ -56,7 +56,7 @@ MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_s
                 "mirt_render_pt_dev", "mirt_render_pttest", "mirt_render_pttest_dev", "mirt_capture_rays_dev", "mirt_device_info"]
 MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
-                 "mirth_describe", "mirth_upload", "mirth_render", "mirth_fill_intersect", "mirth_test_visibility", "mirth_world_vertex", "mirth_normal_transform",
+                 "mirth_describe", "mirth_upload", "mirth_render", "mirth_render_progressive", "mirth_fill_intersect", "mirth_test_visibility", "mirth_world_vertex", "mirth_normal_transform",
                  "mirth_shutdown",
                  "mirth_save_pfm", "mirth_load_pfm"]
 
@@ -121,6 +121,8 @@ def lib():
         L.mirth_upload.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.mirth_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(RenderStats)]
         L.mirth_fill_intersect.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 8
+        L.mirth_render_progressive.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_char_p, C.c_char_p,
+                                               C.c_void_p, C.POINTER(RenderStats)]
         L.mirth_test_visibility.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
         L.mirth_world_vertex.argtypes = [C.c_void_p] * 3
         L.mirth_world_vertex.restype = None
@@ -225,6 +227,17 @@ class HostScene:
             raise MirtError(lib().mirth_last_error().decode())
         return img, st
 
+    def render_progressive(self, spp, seed=0, output_iter=0, resume_from=None, save_state=None):
+        """Renderer::render with periodic PFM dumps / resumable accumulators; spp = total passes wanted."""
+        cam = self.camera()
+        img = np.zeros((cam.height, cam.width, 3), np.float32)
+        st = RenderStats()
+        enc = lambda p: None if p is None else os.fsencode(str(p))
+        if lib().mirth_render_progressive(self.h, spp, seed, output_iter, enc(resume_from), enc(save_state), _ptr(img),
+                                          C.byref(st)) != 0:
+            raise MirtError(lib().mirth_last_error().decode())
+        return img, st
+
     def fill_intersect(self, o, d, contact, inside):
         o = np.ascontiguousarray(o, np.float32)
         d = np.ascontiguousarray(d, np.float32)
@@ -251,6 +264,14 @@ class HostScene:
                                        _ptr(vis)) != 0:
             raise MirtError(lib().mirth_last_error().decode())
         return vis
+
+
+def save_pfm(path, img):
+    """MCRenderer::saveImagePFM (MCRenderer.cpp:500-518) for an [H, W, 3] float32 image"""
+    img = np.ascontiguousarray(img, np.float32)
+    assert img.ndim == 3 and img.shape[2] == 3
+    if lib().mirth_save_pfm(os.fsencode(str(path)), _ptr(img), img.shape[1], img.shape[0]) != 0:
+        raise MirtError(lib().mirth_last_error().decode())
 
 
 def pack_ids(contact, inside):

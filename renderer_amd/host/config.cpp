@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -216,6 +217,10 @@ void ConfigManager::load(const std::string& configFilePath) {
         throw std::runtime_error("ConfigManager: renderer type '" + typeName +
                                  "' is outside this build (PathTracer / PT / PTHIP / PTtest only)");
     }
+    if (opts->first_node("outputIter")) {  // not in the reference's XML (MCRenderer.h:109 hard-wires 5)
+        renderer->mcRenderer->setOutputIter(atoi(opts->first_node("outputIter")->value()));
+        if (PathTracerHIP* pt = dynamic_cast<PathTracerHIP*>(renderer->mcRenderer)) pt->progressive = true;
+    }
     if (opts->first_node("maxDepth")) renderer->mcRenderer->setMaxDepth(atoi(opts->first_node("maxDepth")->value()));
     if (nodeConfig->first_node("savePath")) renderer->mcRenderer->setSavePath(nodeConfig->first_node("savePath")->value());
 }
@@ -272,30 +277,115 @@ bool MCRenderer::loadImagePFM(const std::string& fileName, std::vector<vec3f>& p
     return ok;
 }
 
+// MCRenderer::showCurrentResult (MCRenderer.cpp:396-437)
+void MCRenderer::showCurrentResult(const std::vector<vec3f>& pixelColors, int w, int h, const unsigned* time,
+                                   const unsigned* iter) const {
+    if (!savePath.empty()) saveImagePFM(savePath, pixelColors, w, h);
+    if (iter && time) {
+        std::string fileName;
+        for (char c : savePath) {
+            if (c == '.') break;
+            fileName.push_back(c);
+        }
+        fileName += "_iter_" + std::to_string(*iter) + "_time_" + std::to_string(*time) + ".pfm";
+        saveImagePFM(fileName, pixelColors, w, h);
+    }
+}
+
 // ---- PathTracerHIP ----------------------------------------------------------------------------------
 // PathTracer::renderPixels (PathTracer.cpp:4-58): spp passes of one sample per pixel, running mean.
-// Here the passes run on the device; the sums come back once and are divided by spp.
+// Here the passes run on the device in slices; the sums come back per slice and are divided by the
+// number of passes they hold.
 std::vector<vec3f> PathTracerHIP::renderPixels(const Camera& camera) {
     MirtContext* ctx = IntersectionHIP::context();
     if (!ctx) throw std::runtime_error("PathTracerHIP::renderPixels: the scene was not loaded to the device");
-    MirtRenderParams p;
-    memset(&p, 0, sizeof p);
-    p.camera = camera.toMirt();
-    p.spp_begin = 0;
-    p.spp_count = spp;
-    p.max_depth = maxDepth;
-    p.seed = seed;
-    p.spp_per_launch = sppPerLaunch;
     const size_t npix = (size_t)camera.width * camera.height;
-    std::vector<float> sum(3 * npix);
-    if (launch(ctx, &p, sum.data(), &lastStats) != MIRT_OK)
-        throw std::runtime_error(std::string("PathTracerHIP::renderPixels: ") + mirt_last_error(ctx));
+    if (!resume || sums.size() != 3 * npix) {
+        sums.assign(3 * npix, 0.f);
+        sppDone = 0;
+    }
+    resume = false;
+    lastStats = MirtRenderStats{};
     std::vector<vec3f> pixelColors(npix);
-    const float inv = spp ? 1.f / float(spp) : 0.f;
-    for (size_t i = 0; i < npix; i++)
-        pixelColors[i] = vec3f(sum[3 * i] * inv, sum[3 * i + 1] * inv, sum[3 * i + 2] * inv);
-    if (!savePath.empty()) saveImagePFM(savePath, pixelColors, camera.width, camera.height);
+    auto mean = [&]() {
+        const float inv = sppDone ? 1.f / float(sppDone) : 0.f;
+        for (size_t i = 0; i < npix; i++)
+            pixelColors[i] = vec3f(sums[3 * i] * inv, sums[3 * i + 1] * inv, sums[3 * i + 2] * inv);
+    };
+    const auto t_start = std::chrono::steady_clock::now();
+    std::vector<float> slice(3 * npix);
+    while (sppDone < spp) {
+        // progressive: stop after the next pass s with s % outputIter == 0 (PathTracer.cpp:47), s = sppDone + n - 1
+        unsigned n = spp - sppDone;
+        if (progressive && outputIter > 0) {
+            const unsigned k = (unsigned)outputIter;
+            const unsigned next = ((sppDone + k - 1) / k) * k;  // first s >= sppDone with s % k == 0
+            n = std::min(n, next - sppDone + 1);
+        }
+        MirtRenderParams p;
+        memset(&p, 0, sizeof p);
+        p.camera = camera.toMirt();
+        p.spp_begin = sppDone;
+        p.spp_count = n;
+        p.max_depth = maxDepth;
+        p.seed = seed;
+        p.spp_per_launch = sppPerLaunch;
+        MirtRenderStats st{};
+        if (launch(ctx, &p, slice.data(), &st) != MIRT_OK)
+            throw std::runtime_error(std::string("PathTracerHIP::renderPixels: ") + mirt_last_error(ctx));
+        for (size_t i = 0; i < 3 * npix; i++) sums[i] += slice[i];
+        sppDone += n;
+        lastStats.n_samples += st.n_samples;
+        lastStats.n_rays += st.n_rays;
+        lastStats.n_shadow_rays += st.n_shadow_rays;
+        lastStats.gpu_ms += st.gpu_ms;
+        lastStats.intersect_ms += st.intersect_ms;
+        if (progressive && outputIter > 0 && (sppDone - 1) % (unsigned)outputIter == 0) {
+            mean();
+            unsigned s = sppDone - 1;
+            unsigned nowTime = (unsigned)std::chrono::duration_cast<std::chrono::seconds>(
+                                   std::chrono::steady_clock::now() - t_start).count();
+            showCurrentResult(pixelColors, camera.width, camera.height, &nowTime, &s);
+        }
+    }
+    mean();
+    showCurrentResult(pixelColors, camera.width, camera.height);
     return pixelColors;
+}
+
+// accumulator file: "MIRTACC1", then uint32 {width, height, sppDone, seed, maxDepth}, then W*H*3 fp32 sums
+void PathTracerHIP::saveState(const std::string& fileName, const Camera& camera) const {
+    const size_t npix = (size_t)camera.width * camera.height;
+    if (sums.size() != 3 * npix) throw std::runtime_error("saveState: no accumulators for this camera");
+    FILE* f = fopen(fileName.c_str(), "wb");
+    if (!f) throw std::runtime_error("saveState: cannot open " + fileName);
+    const uint32_t hdr[5] = {(uint32_t)camera.width, (uint32_t)camera.height, sppDone, seed, maxDepth};
+    bool ok = fwrite("MIRTACC1", 1, 8, f) == 8 && fwrite(hdr, 4, 5, f) == 5 &&
+              fwrite(sums.data(), sizeof(float), sums.size(), f) == sums.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) throw std::runtime_error("saveState: short write to " + fileName);
+}
+
+void PathTracerHIP::loadState(const std::string& fileName, const Camera& camera) {
+    FILE* f = fopen(fileName.c_str(), "rb");
+    if (!f) throw std::runtime_error("loadState: cannot open " + fileName);
+    char magic[8];
+    uint32_t hdr[5];
+    std::vector<float> in;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "MIRTACC1", 8) == 0 && fread(hdr, 4, 5, f) == 5;
+    if (ok) {
+        if (hdr[0] != (uint32_t)camera.width || hdr[1] != (uint32_t)camera.height || hdr[3] != seed || hdr[4] != maxDepth) {
+            fclose(f);
+            throw std::runtime_error("loadState: " + fileName + " was written for another image size, seed or maxDepth");
+        }
+        in.resize((size_t)hdr[0] * hdr[1] * 3);
+        ok = fread(in.data(), sizeof(float), in.size(), f) == in.size();
+    }
+    fclose(f);
+    if (!ok) throw std::runtime_error("loadState: " + fileName + " is not an accumulator file");
+    sums.swap(in);
+    sppDone = hdr[2];
+    resume = true;
 }
 
 int PathTracerHIP::launch(MirtContext* ctx, const MirtRenderParams* p, float* rgb_sum, MirtRenderStats* stats) {

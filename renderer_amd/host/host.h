@@ -198,6 +198,13 @@ public:
     // MCRenderer::testVisibility (MCRenderer.cpp:106-118), a one-ray batch on the device
     bool testVisibility(const Ray& startRay, const Ray& endRay);
     // PFM writer with the reference's layout (MCRenderer.cpp:500-518)
+    void setOutputIter(int n) { outputIter = n; }
+    int getOutputIter() const { return outputIter; }
+    // MCRenderer::showCurrentResult (MCRenderer.cpp:396-437) without the OpenCV window: writes the
+    // running mean to savePath; with time and iter also "<savePath up to its first '.'>_iter_<iter>_time_<time>.pfm",
+    // the series compare.cpp:167-251 turns into an iteration / time / RMSE table
+    void showCurrentResult(const std::vector<vec3f>& pixelColors, int w, int h, const unsigned* time = nullptr,
+                           const unsigned* iter = nullptr) const;
     static void saveImagePFM(const std::string& fileName, const std::vector<vec3f>& pixels, int w, int h);
     static bool loadImagePFM(const std::string& fileName, std::vector<vec3f>& pixels, int& w, int& h);
 };
@@ -209,6 +216,19 @@ public:
     unsigned spp = 64;
     unsigned seed = 1;
     unsigned sppPerLaunch = 0;
+    // Progressive output (PathTracer.cpp:47-55): when set, the image is dumped after every pass s with
+    // s % outputIter == 0, as the reference does, i.e. the passes run in slices 1, outputIter, outputIter, ...
+    // Slicing does not change the image: sample streams are keyed by the global sample index.
+    bool progressive = false;
+    // Resumable accumulators (the reference has none): radiance SUMS + the number of passes they hold.
+    // renderPixels continues after sppDone; saveState / loadState move them through a file.
+    // A render starts from zero unless `resume` is set (loadState sets it; it is cleared by the render).
+    std::vector<float> sums;
+    unsigned sppDone = 0;
+    bool resume = false;
+    void saveState(const std::string& fileName, const Camera& camera) const;
+    void loadState(const std::string& fileName, const Camera& camera);  // throws on a mismatching image / seed / depth
+    void resetState() { sums.clear(); sppDone = 0; }
     MirtRenderStats lastStats{};
     explicit PathTracerHIP(Renderer* r) : MCRenderer(r) {}
     std::vector<vec3f> renderPixels(const Camera& camera) override;

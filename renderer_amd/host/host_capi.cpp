@@ -205,6 +205,37 @@ int mirth_render(MirthScene* s, uint32_t spp, uint32_t seed, float* rgb_mean, Mi
     })
 }
 
+int mirth_render_progressive(MirthScene* s, uint32_t spp, uint32_t seed, int32_t output_iter, const char* resume_from,
+                             const char* save_state, float* rgb_mean, MirtRenderStats* stats) {
+    if (!s || !rgb_mean) return -1;
+    GUARD({
+        IntersectionHIP::init();
+        IntersectionHIP::loadKDTreeToDevice(s->renderer.scene);
+        if (!s->renderer.mcRenderer) s->renderer.mcRenderer = new PathTracerHIP(&s->renderer);
+        PathTracerHIP* pt = dynamic_cast<PathTracerHIP*>(s->renderer.mcRenderer);
+        if (!pt) throw std::runtime_error("mirth_render_progressive: the configured integrator is not a path tracer");
+        if (spp) pt->spp = spp;
+        if (seed) pt->seed = seed;
+        const bool was = pt->progressive;
+        const int old_iter = pt->getOutputIter();
+        if (output_iter > 0) {
+            pt->progressive = true;
+            pt->setOutputIter(output_iter);
+        }
+        if (resume_from && *resume_from) pt->loadState(resume_from, s->renderer.camera);
+        std::vector<vec3f> px = s->renderer.render();
+        pt->progressive = was;
+        pt->setOutputIter(old_iter);
+        if (save_state && *save_state) pt->saveState(save_state, s->renderer.camera);
+        for (size_t i = 0; i < px.size(); i++) {
+            rgb_mean[3 * i] = px[i].x;
+            rgb_mean[3 * i + 1] = px[i].y;
+            rgb_mean[3 * i + 2] = px[i].z;
+        }
+        if (stats) *stats = pt->lastStats;
+    })
+}
+
 int mirth_fill_intersect(MirthScene* s, size_t n, const float* o, const float* d, const int32_t* contact,
                          const int32_t* inside, float* dist, int32_t* tid, int32_t* obj, int32_t* local) {
     if (!s || !o || !d || !dist || !tid) return -1;

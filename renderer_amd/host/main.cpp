@@ -1,5 +1,6 @@
 // main.cpp — command-line shell in the shape of the reference's main.cpp:10-17 / Renderer.cpp:52-62:
 // load a config, render, write the PFM. Usage: mirt_render [Data/Config.xml] [--spp N] [--seed S] [--out file.pfm]
+//        [--output-iter K] (periodic dumps, PathTracer.cpp:47-55) [--resume acc.bin] [--save-state acc.bin]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,12 +12,16 @@
 using namespace mirt_host;
 
 int main(int argc, char** argv) {
-    std::string config = "Data/Config.xml", out;
+    std::string config = "Data/Config.xml", out, resume, save_state;
     unsigned spp = 0, seed = 0;
+    int output_iter = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--spp") && i + 1 < argc) spp = (unsigned)atoi(argv[++i]);
         else if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = (unsigned)atoi(argv[++i]);
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
+        else if (!strcmp(argv[i], "--output-iter") && i + 1 < argc) output_iter = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--resume") && i + 1 < argc) resume = argv[++i];
+        else if (!strcmp(argv[i], "--save-state") && i + 1 < argc) save_state = argv[++i];
         else config = argv[i];
     }
     try {
@@ -26,7 +31,13 @@ int main(int argc, char** argv) {
         if (pt && spp) pt->spp = spp;
         if (pt && seed) pt->seed = seed;
         if (!out.empty()) renderer.mcRenderer->setSavePath(out);
+        if (pt && output_iter > 0) {
+            pt->progressive = true;
+            pt->setOutputIter(output_iter);
+        }
+        if (pt && !resume.empty()) pt->loadState(resume, renderer.camera);
         std::vector<vec3f> px = renderer.render();
+        if (pt && !save_state.empty()) pt->saveState(save_state, renderer.camera);
         if (pt) {
             const MirtRenderStats& st = pt->lastStats;
             printf("samples %llu rays %llu gpu %.3f ms (intersect %.3f ms) -> %.2f Msamples/s %.2f Mrays/s\n",

@@ -141,3 +141,36 @@ def test_capture_rays(gpu, cornell, cornell_oracle, ra):
     tg, ig = gpu.intersect(o, d, a, ra.MODE_NO_SELF)
     tc, ic = cornell_oracle.intersect(o, d, a, ra.MODE_NO_SELF, threads=16)
     assert (ig == ic).mean() >= 0.9999
+
+
+def test_progressive_output_and_resume(ra, cornell_oracle, tmp_path):
+    """PathTracer.cpp:47-55 / MCRenderer::showCurrentResult: dumps after every pass s with
+    s % outputIter == 0, named <stem>_iter_<s>_time_<sec>.pfm; slicing and resuming from saved
+    accumulators give the image of one uninterrupted render (streams are keyed by global sample)."""
+    from renderer_amd import compare
+
+    s = ra.HostScene.load_config(os.path.join(ROOT, "Data", "Config_Glossy128.xml"))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        whole, st0 = s.render(spp=23, seed=2)
+        prog, st1 = s.render_progressive(23, seed=2, output_iter=5)
+        names = sorted(n for n in os.listdir(".") if "_iter_" in n)
+        first, _ = s.render_progressive(9, seed=2, save_state="acc.bin")
+        rest, st2 = s.render_progressive(23, seed=2, resume_from="acc.bin")
+        with pytest.raises(ra.MirtError, match="another image size, seed"):
+            s.render_progressive(23, seed=3, resume_from="acc.bin")
+        table = compare.rmse_table(".", "cornell.pfm")
+    finally:
+        os.chdir(cwd)
+    iters = sorted(compare.parse_iter_time(n)[0] for n in names)
+    assert iters == [0, 5, 10, 15, 20]
+    assert np.abs(prog - whole).max() <= 1e-5 * max(1.0, whole.max())
+    assert np.abs(rest - whole).max() <= 1e-5 * max(1.0, whole.max())
+    assert st1.n_samples == st0.n_samples and st1.n_rays == st0.n_rays
+    assert st2.n_samples == 128 * 128 * 14  # only the missing passes were rendered
+    c, _ = cornell_oracle.render(s.camera(), 9, seed=2, threads=16)
+    assert rmse(first, c / 9) < 5e-3
+    # the convergence table compare.cpp builds from the series: RMSE against the final image falls
+    assert [r[0] for r in table] == iters and table[0][2] > table[-1][2]
+    s.close()

@@ -178,3 +178,34 @@ def test_pack_ids_and_shards(ra):
         assert parts[0][0] == 0 and sum(c for _, c in parts) == spp
         for (b0, c0), (b1, _) in zip(parts, parts[1:]):
             assert b0 + c0 == b1
+
+
+def test_compare_tool(ra, tmp_path):
+    """renderer_amd.compare = compare.cpp: clamped PFM read, RMSE over pixels, iter/time table"""
+    from renderer_amd import compare
+
+    rng = np.random.default_rng(4)
+    ref = rng.uniform(0, 2, (6, 9, 3)).astype(np.float32)
+    ra.save_pfm(str(tmp_path / "ref.pfm"), ref)
+    got = compare.read_pfm(str(tmp_path / "ref.pfm"))
+    assert np.array_equal(got, np.clip(ref, 0, 1))
+    assert np.array_equal(compare.read_pfm(str(tmp_path / "ref.pfm"), clamp=False), ref)
+    series = tmp_path / "series"
+    series.mkdir()
+    for it, tm, noise in ((10, 3, 0.05), (0, 0, 0.3), (5, 1, 0.1)):
+        ra.save_pfm(str(series / ("img_iter_%d_time_%d.pfm" % (it, tm))), ref + noise)
+    ra.save_pfm(str(series / "img.pfm"), ref)  # no iter/time in the name: ignored
+    rows = compare.rmse_table(str(series), str(tmp_path / "ref.pfm"))
+    assert [r[:2] for r in rows] == [(0, 0), (5, 1), (10, 3)]
+    exp = [compare.rmse(np.clip(ref + n, 0, 1), np.clip(ref, 0, 1)) for n in (0.3, 0.1, 0.05)]
+    assert np.allclose([r[2] for r in rows], exp)
+    assert rows[0][2] > rows[1][2] > rows[2][2]
+    assert compare.parse_iter_time("cornell_iter_15_time_7.pfm") == (15, 7)
+    # mask file: bottom row first, 1 = counted
+    mask = np.zeros((6, 9), np.int64)
+    mask[0, :] = 1  # top image row
+    np.savetxt(tmp_path / "mask.txt", mask[::-1], fmt="%d")
+    a = np.clip(ref, 0, 1).copy()
+    a[0] = 0
+    assert np.isclose(compare.rmse(a, np.clip(ref, 0, 1), compare.read_mask(str(tmp_path / "mask.txt"), 9, 6)),
+                      np.sqrt((np.clip(ref[0], 0, 1).astype(np.float64) ** 2).sum() / 9))
