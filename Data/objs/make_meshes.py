@@ -6,6 +6,8 @@ rules (SimpleShape.cpp:65-189): triangles only, 3 numbers per v / vn line, faces
   plane.obj  unit square on y = 0 spanning [-1,1]^2 in x,z, normal +y (2 triangles, one vn)
   ball.obj   UV sphere, 32 x 16 (960 triangles), per-vertex normals = positions
   cube.obj   [-1,1]^3, 12 triangles, outward winding, no vertex normals (flat)
+  spot_light2.obj  two groups for <GroupObject> (Data/Scene_Fog.xml): "light", a square on y = 0 with normal
+             +y, and "frame", a four-sided shade around it from y = 0 to y = 1 whose faces look inward
 Run:  python3 Data/objs/make_meshes.py   (writes next to this file; output is committed)
 """
 import math, os
@@ -69,4 +71,27 @@ for q in quads:
         if sum(n[k] * cen[k] for k in range(3)) < 0: t = (t[0], t[2], t[1])
         cf.append(((t[0], 0), (t[1], 0), (t[2], 0)))
 write("cube.obj", cv, [], cf)
+
+# spot_light2: every group declares its own v / vn after its g line (the loader rebases a group's face
+# indices to the counts at that line, SimpleShape.cpp:85-96, 142-155); indices stay file-global
+with open(os.path.join(here, "spot_light2.obj"), "w") as f:
+    f.write("# authored by Data/objs/make_meshes.py\n")
+    f.write("g light\n")
+    a = 0.6
+    for v in ((-a, 0.0, -a), (-a, 0.0, a), (a, 0.0, a), (a, 0.0, -a)): f.write("v %.9g %.9g %.9g\n" % v)
+    f.write("vn 0 1 0\n")
+    f.write("f 1//1 2//1 3//1\nf 1//1 3//1 4//1\n")
+    f.write("g frame\n")
+    nv, nn = 4, 1
+    sides = [((-1, 0, -1), (-1, 0, 1), (-1, 1, 1), (-1, 1, -1), (1, 0, 0)),
+             ((1, 0, -1), (1, 0, 1), (1, 1, 1), (1, 1, -1), (-1, 0, 0)),
+             ((-1, 0, -1), (1, 0, -1), (1, 1, -1), (-1, 1, -1), (0, 0, 1)),
+             ((-1, 0, 1), (1, 0, 1), (1, 1, 1), (-1, 1, 1), (0, 0, -1))]
+    for q in sides:
+        for v in q[:4]: f.write("v %.9g %.9g %.9g\n" % tuple(float(x) for x in v))
+        f.write("vn %.9g %.9g %.9g\n" % tuple(float(x) for x in q[4]))
+    for k in range(4):
+        b, n = nv + 4 * k, nn + 1 + k
+        f.write("f %d//%d %d//%d %d//%d\n" % (b + 1, n, b + 2, n, b + 3, n))
+        f.write("f %d//%d %d//%d %d//%d\n" % (b + 1, n, b + 3, n, b + 4, n))
 print("wrote plane.obj (2 tris), ball.obj (%d tris), cube.obj (%d tris)" % (len(faces), len(cf)))

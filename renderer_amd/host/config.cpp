@@ -90,13 +90,16 @@ static void setColor(float dst[3], const vec3f& v) {
 }
 
 // ConfigManager.cpp:25-164 with the defaults of the Scene*Object constructors
-SceneObject* ConfigManager::generateSceneObject(XmlNode* nodeObj, XmlNode* nodeMat) {
+SceneObject* ConfigManager::generateSceneObject(XmlNode* nodeObj, XmlNode* nodeMat, const SimpleShape* shape) {
     XmlNode* typeNode = nodeMat->first_node("type");
     if (!typeNode) throw std::runtime_error("ConfigManager: <Material> without <type>");
     const std::string type = typeNode->value();
     std::unique_ptr<SceneObject> obj(new SceneObject(&renderer->scene));
     MirtObject& m = obj->material;
     if (nodeObj->first_node("transform")) obj->setTransform(readMatrix(nodeObj->first_node("transform")->value()));
+    // a <GroupObject> member takes its mesh AND transform from the split shape (ConfigManager.cpp:34-35:
+    // the assignment comes after setTransform, so the member's own <transform> is overwritten)
+    if (shape) *static_cast<SimpleShape*>(obj.get()) = *shape;
     if (nodeMat->first_node("BumpTexture") || nodeMat->first_node("Texture") ||
         nodeMat->first_node("ColorTexture") || nodeMat->first_node("CoeffTexture"))
         throw std::runtime_error("ConfigManager: image / bump textures are outside this build (constant colours only)");
@@ -155,8 +158,35 @@ void ConfigManager::load(const std::string& configFilePath) {
     if (!nodeScene) throw std::runtime_error("ConfigManager: scene '" + pn.second + "' not found");
     currentPath = pn.first;
 
-    if (nodeScene->first_node("GroupObject"))
-        throw std::runtime_error("ConfigManager: <GroupObject> is outside this build");
+    // <GroupObject> (ConfigManager.cpp:192-226): one .obj split at its "g" lines into named sub-shapes,
+    // each member <Object Name="..."> taking the sub-shape of that name; group members come first
+    for (XmlNode* nodeGroup = nodeScene->first_node("GroupObject"); nodeGroup; nodeGroup = nodeGroup->next_sibling("GroupObject")) {
+        if (!nodeGroup->first_node("filePath")) throw std::runtime_error("ConfigManager: <GroupObject> without <filePath>");
+        const std::string path = resolve(nodeGroup->first_node("filePath")->value());
+        SimpleShape ss;
+        if (nodeGroup->first_node("transform")) ss.setTransform(readMatrix(nodeGroup->first_node("transform")->value()));
+        std::vector<SimpleShape*> shapes;
+        ss.loadShape(path, true, &shapes);
+        struct Owner {
+            std::vector<SimpleShape*>& v;
+            ~Owner() { for (SimpleShape* p : v) delete p; }
+        } owner{shapes};
+        std::map<std::string, SimpleShape*> name_shape;
+        for (SimpleShape* p : shapes) name_shape[p->name] = p;
+        for (XmlNode* nodeObj = nodeGroup->first_node("Object"); nodeObj; nodeObj = nodeObj->next_sibling("Object")) {
+            XmlNode* matRef = nodeObj->first_node("Material");
+            if (!matRef) throw std::runtime_error("ConfigManager: <Object> without <Material>");
+            pn = getPathAndName(matRef);
+            XmlNode* nodeMat = findNode(pn.first, "Material", pn.second);
+            if (!nodeMat && matRef->first_node("name")) nodeMat = findNode(nodeScene, "Material", pn.second);
+            if (!nodeMat) nodeMat = matRef;
+            const std::string* nm = nodeObj->first_attribute("Name");
+            if (!nm || !name_shape.count(*nm))  // the reference dereferences a NULL shape here
+                throw std::runtime_error("ConfigManager: <GroupObject> member '" + (nm ? *nm : std::string("?")) +
+                                         "' has no group of that name in " + path);
+            renderer->scene.objects.push_back(generateSceneObject(nodeObj, nodeMat, name_shape[*nm]));
+        }
+    }
 
     for (XmlNode* nodeObj = nodeScene->first_node("Object"); nodeObj; nodeObj = nodeObj->next_sibling("Object")) {
         XmlNode* matRef = nodeObj->first_node("Material");

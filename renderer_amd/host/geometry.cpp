@@ -20,9 +20,14 @@ void SimpleShape::getBoundingBox(vec3f& lo, vec3f& hi) const {
         }
 }
 
-// SimpleShape.cpp:257-272: recentre on the box centre, scale the longest extent to [-1, 1]
-void SimpleShape::unitize() {
-    if (vertexList.empty()) return;
+// SimpleShape.cpp:257-272: recentre on the box centre, scale the longest extent to [-1, 1].
+// Returns the matrix the reference returns. Its 16-argument constructor fills COLUMN-major memory
+// (nvMatrix.h:98-106), so the "translation" arguments land in the bottom row: applied to a point the
+// matrix only scales by 2/maxLen. <GroupObject> sub-shapes are unitized through this matrix
+// (SimpleShape.cpp:186-194) and therefore are scaled but not recentred; kept as it is.
+matrix4 SimpleShape::unitize() {
+    matrix4 u;
+    if (vertexList.empty()) return u;
     vec3f lo, hi;
     getBoundingBox(lo, hi);
     vec3f center = (lo + hi) / 2;
@@ -33,6 +38,19 @@ void SimpleShape::unitize() {
         v = v - center;
         v = v / (maxLen / 2);
     }
+    u(0, 0) = u(1, 1) = u(2, 2) = 2 / maxLen;
+    u(3, 0) = -2 / maxLen * center.x;
+    u(3, 1) = -2 / maxLen * center.y;
+    u(3, 2) = -2 / maxLen * center.z;
+    return u;
+}
+
+// SimpleShape.cpp:222-236
+void SimpleShape::applyTransform() {
+    matrix4 normalMat = transform.inverse().transposed();
+    for (auto& v : vertexList) v = transform.apply(v, 1.f);
+    for (auto& n : vertexNormalList) n = normalMat.apply(n, 0.f);
+    transform.make_identity();
 }
 
 // Face token forms a, a/b, a/b/c, a//c with 1-based indices (SimpleShape.cpp:116-139). Returns the
@@ -52,10 +70,13 @@ static void parseFaceToken(const char* tok, unsigned& v, unsigned& t, unsigned& 
     }
 }
 
-// SimpleShape.cpp:44-220 for ".obj" without group splitting. Rules kept: '#' lines are skipped; a
+// SimpleShape.cpp:44-220 for ".obj". Rules kept: '#' lines are skipped; a
 // line counts only if it has at least 4 whitespace-separated tokens and only the first 4 are read
 // (faces must be triangles; "vt" needs 3 numbers); no material handling.
-void SimpleShape::loadShape(const std::string& fileName, bool normalize) {
+void SimpleShape::loadShape(const std::string& fileName, bool normalize, std::vector<SimpleShape*>* splitShapes) {
+    const bool split = splitShapes != nullptr;
+    SimpleShape* shape = nullptr;
+    unsigned current_fi = 0, current_fni = 0, current_fti = 0;
     vertexList.clear();
     faceVertexIndexList.clear();
     vertexNormalList.clear();
@@ -70,18 +91,30 @@ void SimpleShape::loadShape(const std::string& fileName, bool normalize) {
     while (fgets(line, sizeof line, file)) {
         if (line[0] == '#') continue;
         int num = sscanf(line, "%1023s %1023s %1023s %1023s", attrib, parms[0], parms[1], parms[2]);
+        if (num >= 2 && strcmp("g", attrib) == 0 && split) {  // SimpleShape.cpp:85-96
+            if (shape) splitShapes->push_back(shape);
+            shape = new SimpleShape;
+            shape->name = parms[0];
+            current_fi = (unsigned)vertexList.size();
+            current_fni = (unsigned)vertexNormalList.size();
+            current_fti = (unsigned)vertexTexCoordList.size();
+        }
         if (num != 4) continue;
         if (strcmp("v", attrib) == 0 || strcmp("vn", attrib) == 0 || strcmp("vt", attrib) == 0) {
             vec3f v;
             sscanf(parms[0], "%f", &v.x);
             sscanf(parms[1], "%f", &v.y);
             sscanf(parms[2], "%f", &v.z);
-            if (attrib[1] == 0)
+            if (attrib[1] == 0) {
                 vertexList.push_back(v);
-            else if (attrib[1] == 'n')
+                if (shape) shape->vertexList.push_back(v);
+            } else if (attrib[1] == 'n') {
                 vertexNormalList.push_back(v);
-            else
+                if (shape) shape->vertexNormalList.push_back(v);
+            } else {
                 vertexTexCoordList.push_back(v);
+                if (shape) shape->vertexTexCoordList.push_back(v);
+            }
         } else if (strcmp("f", attrib) == 0) {
             vec3ui tri{0, 0, 0}, vn{0, 0, 0}, vt{0, 0, 0};
             int got3 = 0, got2 = 0;
@@ -97,18 +130,60 @@ void SimpleShape::loadShape(const std::string& fileName, bool normalize) {
             faceVertexIndexList.push_back(tri);
             if (has_n) faceVertexNormalIndexList.push_back(vn);
             if (has_t) faceVertexTexCoordIndexList.push_back(vt);
+            if (shape) {
+                shape->faceVertexIndexList.push_back(vec3ui{tri.x - current_fi, tri.y - current_fi, tri.z - current_fi});
+                if (has_n)
+                    shape->faceVertexNormalIndexList.push_back(vec3ui{vn.x - current_fni, vn.y - current_fni, vn.z - current_fni});
+                if (has_t)
+                    shape->faceVertexTexCoordIndexList.push_back(vec3ui{vt.x - current_fti, vt.y - current_fti, vt.z - current_fti});
+            }
         }
     }
     fclose(file);
+    if (shape) splitShapes->push_back(shape);
+    auto dropSplit = [&]() {
+        if (!split) return;
+        for (SimpleShape* p : *splitShapes) delete p;
+        splitShapes->clear();
+    };
+    if (split)  // a face that refers to a vertex of an earlier group cannot be rebased: refuse it
+        for (SimpleShape* p : *splitShapes) {
+            bool bad = false;
+            for (auto& f : p->faceVertexIndexList)
+                for (int k = 0; k < 3; k++) bad |= f[k] >= p->vertexList.size();
+            for (auto& f : p->faceVertexNormalIndexList)
+                for (int k = 0; k < 3; k++) bad |= f[k] >= p->vertexNormalList.size();
+            if (bad) {
+                std::string nm = p->name;
+                dropSplit();
+                throw std::runtime_error("loadShape: group '" + nm + "' in " + fileName +
+                                         " uses vertices declared before its g line");
+            }
+        }
     for (auto& f : faceVertexIndexList)
         for (int k = 0; k < 3; k++)
             if (f[k] >= vertexList.size())
+            {
+                dropSplit();
                 throw std::runtime_error("loadShape: face index out of range in " + fileName);
+            }
     for (auto& f : faceVertexNormalIndexList)
         for (int k = 0; k < 3; k++)
             if (f[k] >= vertexNormalList.size())
+            {
+                dropSplit();
                 throw std::runtime_error("loadShape: normal index out of range in " + fileName);
-    if (normalize) unitize();
+            }
+    if (normalize) {
+        const matrix4 unitizeMat = unitize();
+        if (split)  // SimpleShape.cpp:186-194
+            for (SimpleShape* p : *splitShapes) {
+                p->setTransform(unitizeMat);
+                p->applyTransform();
+                p->setTransform(transform);
+                p->getBoundingBox(p->minCoord, p->maxCoord);
+            }
+    }
     getBoundingBox(minCoord, maxCoord);
 }
 

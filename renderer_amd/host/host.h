@@ -60,8 +60,12 @@ public:
     unsigned getTriangleNum() const { return (unsigned)faceVertexIndexList.size(); }
     void getBoundingBox(vec3f& lo, vec3f& hi) const;
     // throws std::runtime_error when the file cannot be read or is not a triangle .obj
-    void loadShape(const std::string& fileName, bool normalize = true);
-    void unitize();
+    // splitShapes != nullptr: <GroupObject> mode (SimpleShape.cpp:85-96): every "g name" line starts a
+    // new sub-shape that receives the vertices / normals / faces that follow it (indices rebased to the
+    // counts at the "g" line); the caller owns the returned shapes
+    void loadShape(const std::string& fileName, bool normalize = true, std::vector<SimpleShape*>* splitShapes = nullptr);
+    matrix4 unitize();           // returns SimpleShape.cpp:270's matrix (see geometry.cpp)
+    void applyTransform();       // SimpleShape.cpp:222-236
     // world-space corner normals of face fi, transformed by transpose(inverse(transform)) and NOT
     // normalised (what SimpleShape::getWorldNormal interpolates, SimpleShape.cpp:310,317-323);
     // false when the shape has no usable vertex normals (flat shading)
@@ -263,7 +267,7 @@ private:
     XmlNode* findNode(const std::string& filePath, const std::string& nodeTag, const std::string& nodeName);
     XmlNode* findNode(XmlNode* root, const std::string& nodeTag, const std::string& nodeName);
     std::pair<std::string, std::string> getPathAndName(XmlNode* node);
-    SceneObject* generateSceneObject(XmlNode* nodeObj, XmlNode* nodeMat);
+    SceneObject* generateSceneObject(XmlNode* nodeObj, XmlNode* nodeMat, const SimpleShape* shape = nullptr);
     std::string resolve(const std::string& path) const;
 };
 

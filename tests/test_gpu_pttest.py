@@ -39,7 +39,7 @@ def test_cornell_glossy_pttest_parity(gpu, cornell, cornell_oracle):
 
 
 def test_other_scenes_pttest_parity(gpu, ra, orc):
-    for cfg in ("Config_Balls2_128.xml", "Config_Cube128.xml"):
+    for cfg in ("Config_Balls2_128.xml", "Config_Cube128.xml", "Config_SpotLight128.xml"):
         s = ra.HostScene.load_config(os.path.join(ROOT, "Data", cfg))
         S = orc.OracleScene(s.raw())
         gpu.upload(s.describe())

@@ -209,3 +209,49 @@ def test_compare_tool(ra, tmp_path):
     a[0] = 0
     assert np.isclose(compare.rmse(a, np.clip(ref, 0, 1), compare.read_mask(str(tmp_path / "mask.txt"), 9, 6)),
                       np.sqrt((np.clip(ref[0], 0, 1).astype(np.float64) ** 2).sum() / 9))
+
+
+def test_group_object_split(ra, tmp_path):
+    """<GroupObject> (ConfigManager.cpp:192-226, SimpleShape.cpp:85-96,186-194): one .obj split at its g
+    lines; members come before the plain objects, take the group's transform (their own <transform> is
+    overwritten, ConfigManager.cpp:32-35) and are scaled by the WHOLE file's unitize factor without being
+    recentred (the unitize matrix carries its translation in the bottom row)."""
+    s = ra.HostScene.load_config(os.path.join(DATA, "Config_SpotLight128.xml"))
+    raw = s.raw()
+    assert s.n_objects == 8 and s.n_tris == 2 + 8 + 960 + 5 * 2
+    assert raw["objects"]["type"][0] == ra.OBJ_EMISSIVE and raw["objects"]["type"][1] == ra.OBJ_DIFFUSE
+    tri_obj, tris, verts = raw["tri_obj"], raw["tris"].astype(np.int64), raw["verts"]
+    light = verts[np.unique(tris[tri_obj == 0])]
+    frame = verts[np.unique(tris[tri_obj == 1])]
+    # group transform [0.2,0,0,0][0,-0.2,0,0.88][0,0,0.2,0]; the file spans [-1,1] x [0,1] x [-1,1]: factor 1
+    assert np.allclose(light[:, 1], 0.88) and np.allclose(np.abs(light[:, [0, 2]]), 0.12)
+    assert np.allclose(sorted(set(np.round(frame[:, 1], 6))), [0.68, 0.88]) and np.allclose(np.abs(frame[:, [0, 2]]), 0.2)
+    # the light's shading normal points down (normal matrix of the y-flipping transform)
+    vn = raw["tri_vn"][tri_obj == 0].reshape(-1, 3)
+    assert (vn[:, 1] < 0).all() and np.allclose(vn[:, [0, 2]], 0)
+    s.close()
+    # a scaled, off-centre file: sub-shapes are multiplied by 2/maxLen but keep their offset
+    obj = tmp_path / "g.obj"
+    obj.write_text("g a\nv 2 0 0\nv 6 0 0\nv 2 4 0\nf 1 2 3\ng b\nv 2 0 1\nv 6 0 1\nv 2 4 1\nf 4 5 6\n")
+    cfg = tmp_path / "c.xml"
+    cfg.write_text("<Config><Scene><path>s.xml</path><name>S</name><camera>c</camera></Scene><renderer>PT</renderer></Config>")
+    scn = tmp_path / "s.xml"
+    scn.write_text("<Scene Name=\"S\"><Camera Name=\"c\"><width>4</width><height>4</height><sightDist>4</sightDist>"
+                   "<focus>(0,0,0)</focus><position>(0,0,2)</position><up>(0,1,0)</up></Camera>"
+                   "<GroupObject><filePath>%s</filePath>"
+                   "<Object Name=\"b\"><Material><type>Diffuse</type><color>(1,1,1)</color></Material></Object>"
+                   "<Object Name=\"a\"><Material><type>Emissive</type><color>(1,1,1)</color></Material></Object>"
+                   "</GroupObject></Scene>" % obj)
+    s = ra.HostScene.load_config(str(cfg))
+    raw = s.raw()
+    assert s.n_objects == 2 and raw["objects"]["type"][0] == ra.OBJ_DIFFUSE  # member order, not group order
+    v = raw["verts"][raw["tris"].astype(np.int64)[0]]
+    assert np.allclose(v, np.array([[2, 0, 1], [6, 0, 1], [2, 4, 1]]) * 0.5)  # maxLen 4: factor 2/4
+    s.close()
+    scn.write_text(scn.read_text().replace('Name="b"', 'Name="zz"'))
+    with pytest.raises(ra.MirtError, match="no group of that name"):
+        ra.HostScene.load_config(str(cfg))
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\ng a\nf 1 2 3\n")
+    scn.write_text(scn.read_text().replace('Name="zz"', 'Name="a"'))
+    with pytest.raises(ra.MirtError, match="declared before its g line"):
+        ra.HostScene.load_config(str(cfg))
