@@ -213,7 +213,8 @@ def main():
         traffic_bytes, traffic_src = None, None
         tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_current_traffic.json")
         if os.path.exists(tj) and n_sec == 12582912 and args.workload == "cornell":
-            k = json.load(open(tj))["kernels"].get("k_intersect<2, false, false>")
+            ks = json.load(open(tj))["kernels"]
+            k = next((v for n, v in sorted(ks.items()) if n.startswith("k_intersect<2, false, false")), None)
             if k:
                 traffic_bytes = int(k["read_bytes"] + k["write_bytes"])
                 traffic_src = "profiles/r1_current_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean of %d dispatches)" % k["dispatches"]
