@@ -39,6 +39,11 @@ extern "C" {
                                    = mirror) + RefractiveMaterial.cpp:4-104                  */
 #define MIRT_OBJ_EMISSIVE    3  /* SceneEmissiveObject.cpp:4-19                              */
 #define MIRT_OBJ_VPM         4  /* SceneVPMObject.cpp:4-233 (homogeneous medium)             */
+#define MIRT_OBJ_PHONG       5  /* ScenePhongObject.h:7-23: a glossy and a diffuse material; every
+                                   scatter picks one of the two with equal chance and does NOT divide
+                                   by that chance (SceneObject.cpp:366-373); BSDFs add, pdfs average
+                                   (SceneObject.cpp:227-248, 341-352). color = diffuse, color2 + coeff
+                                   = glossy                                                        */
 
 /* intersection modes */
 #define MIRT_MODE_UNCONDITIONAL 0 /* KDTree::intersect(ray, tid, NULL), KDTree.cpp:335-339    */
@@ -68,6 +73,7 @@ typedef struct MirtObject {
     float   sigma_s[3];    /* VPM                                                            */
     float   sigma_a[3];    /* VPM                                                            */
     float   g;             /* VPM Henyey-Greenstein g                                        */
+    float   color2[3];     /* MIRT_OBJ_PHONG: colour of the glossy component                 */
 } MirtObject;
 
 /* One object's OWN tree (Scene::buildObjKDTrees, Scene.cpp:287-320), same layout as the scene

@@ -582,12 +582,14 @@ struct Tracer {
 
     // DiffuseMaterial.cpp:4-76
     PRay scatterDiffuse(int object, const PRay& in, Stream& rng) const {
+        const OrcObject& o = S.objects[object];
+        return scatterDiffuse(object, V3(o.color[0], o.color[1], o.color[2]), in, rng);
+    }
+    PRay scatterDiffuse(int object, const V3& color, const PRay& in, Stream& rng) const {
         PRay out;
         out.origin = in.origin + in.direction * in.intersectDist;
         LocalFrame lf;
         lf.buildFromNormal(objNormal(in.intersectObject, in.intersectObjectTriangleID, out.origin));
-        const OrcObject& o = S.objects[object];
-        V3 color(o.color[0], o.color[1], o.color[2]);
         V3 normal = lf.n;
         out.insideObject = in.insideObject;
         out.intersectObject = -1;
@@ -620,14 +622,15 @@ struct Tracer {
 
     // GlossyMaterial.cpp:4-56, GlossyBSDF.h:24-33
     PRay scatterGlossy(int object, const PRay& in, Stream& rng) const {
+        const OrcObject& o = S.objects[object];
+        return scatterGlossy(object, V3(o.color[0], o.color[1], o.color[2]), o.coeff, in, rng);
+    }
+    PRay scatterGlossy(int object, const V3& color, float coeff, const PRay& in, Stream& rng) const {
         PRay out;
         V3 position = in.origin + in.direction * in.intersectDist;
         LocalFrame lf;
         lf.buildFromNormal(objNormal(in.intersectObject, in.intersectObjectTriangleID, position));
         V3 normal = lf.n;
-        const OrcObject& o = S.objects[object];
-        V3 color(o.color[0], o.color[1], o.color[2]);
-        float coeff = o.coeff;
         out.insideObject = in.insideObject;
         out.origin = position;
         out.contactObject = object;
@@ -969,6 +972,15 @@ struct Tracer {
             case ORC_REFRACTIVE: return scatterRefractive(object, in, rng);
             case ORC_EMISSIVE: return scatterEmissive(object, in);
             case ORC_VPM: return scatterVPM(object, in, rng);
+            case ORC_PHONG: {
+                // SceneObject.cpp:366-373: materialList[rand() % 2], list = {glossy, diffuse}
+                // (ScenePhongObject.h:16-19); the choice costs one draw of the path's stream and its
+                // probability is NOT divided out
+                const OrcObject& o = S.objects[object];
+                if (rng.genFloat() < 0.5f)
+                    return scatterGlossy(object, V3(o.color2[0], o.color2[1], o.color2[2]), o.coeff, in, rng);
+                return scatterDiffuse(object, V3(o.color[0], o.color[1], o.color[2]), in, rng);
+            }
             default: {
                 PRay dead;  // unsupported kind: terminate the path with zero weight
                 dead.direction = V3(0, 0, 0);
@@ -1228,14 +1240,23 @@ struct Tracer {
             if (dot(lf.n, inRay.direction) <= 0 && dot(lf.n, outRay.direction) >= 0) return color / float(REF_PI);
             return V3(0, 0, 0);
         }
-        if (o.type == ORC_GLOSSY) {
-            float p = std::max(color.x, std::max(color.y, color.z));
+        auto glossy = [&](const V3& gc) {
+            float p = std::max(gc.x, std::max(gc.y, gc.z));
             V3 c(0, 0, 0);
             if (dot(lf.n, inRay.direction) <= 0 && dot(lf.n, outRay.direction) >= 0) {
                 V3 r2 = -dot(lf.n, inRay.direction) * lf.n * 2 + inRay.direction;
-                if (dot(r2, outRay.direction) > 0) c = color * powf(dot(r2, outRay.direction), o.coeff);
+                if (dot(r2, outRay.direction) > 0) c = gc * powf(dot(r2, outRay.direction), o.coeff);
             }
             return p * c;
+        };
+        if (o.type == ORC_GLOSSY) return glossy(color);
+        if (o.type == ORC_PHONG) {  // SceneObject.cpp:341-352: the materials' BSDFs add (glossy first)
+            V3 bsdfColor(0, 0, 0);
+            bsdfColor = bsdfColor + glossy(V3(o.color2[0], o.color2[1], o.color2[2]));
+            V3 dcol(0, 0, 0);
+            if (dot(lf.n, inRay.direction) <= 0 && dot(lf.n, outRay.direction) >= 0) dcol = color / float(REF_PI);
+            bsdfColor = bsdfColor + dcol;
+            return bsdfColor;
         }
         return V3(0, 0, 0);
     }
@@ -1259,6 +1280,23 @@ struct Tracer {
             return cosPdf(lf, outRay.direction, o.coeff);
         }
         if (o.type == ORC_REFRACTIVE) return 1;
+        if (o.type == ORC_PHONG) {  // SceneObject.cpp:239-245: the mean of the materials' densities
+            float prob = 0;
+            {
+                LocalFrame lf;
+                V3 normal = contactNormal(outRay);
+                V3 reflDir = -dot(normal, inRay.direction) * normal * 2 + inRay.direction;
+                lf.buildFromNormal(reflDir);
+                prob += cosPdf(lf, outRay.direction, o.coeff);
+            }
+            {
+                LocalFrame lf;
+                lf.buildFromNormal(objNormal(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin));
+                float p = std::max(o.color[0], std::max(o.color[1], o.color[2]));
+                prob += p * cosPdf(lf, outRay.direction, 1.f);
+            }
+            return prob / 2;
+        }
         return 0;
     }
 

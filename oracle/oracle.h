@@ -31,6 +31,7 @@ extern "C" {
 #define ORC_REFRACTIVE 2
 #define ORC_EMISSIVE 3
 #define ORC_VPM 4
+#define ORC_PHONG 5
 
 typedef struct OrcObject {
     int32_t type, has_vn, volumetric, tri_begin, tri_count;
@@ -41,6 +42,7 @@ typedef struct OrcObject {
     float sigma_s[3];
     float sigma_a[3];
     float g;
+    float color2[3]; /* ORC_PHONG: glossy colour (color = diffuse) */
 } OrcObject;
 
 typedef struct OrcCamera {

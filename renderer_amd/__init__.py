@@ -15,15 +15,15 @@ LIB_PATH = os.environ.get("MIRT_LIB") or os.path.join(_HERE, "libmirt.so")  # MI
 REPO_ROOT = os.path.dirname(_HERE)
 DATA_DIR = os.path.join(REPO_ROOT, "Data")
 
-OBJ_DIFFUSE, OBJ_GLOSSY, OBJ_REFRACTIVE, OBJ_EMISSIVE, OBJ_VPM = range(5)
+OBJ_DIFFUSE, OBJ_GLOSSY, OBJ_REFRACTIVE, OBJ_EMISSIVE, OBJ_VPM, OBJ_PHONG = range(6)
 MODE_UNCONDITIONAL, MODE_LAST_TID, MODE_NO_SELF = range(3)
 
 # MirtObject as a numpy structured dtype (same layout as the C struct; also the oracle's OrcObject)
 OBJECT_DTYPE = np.dtype(
     [("type", "<i4"), ("has_vn", "<i4"), ("volumetric", "<i4"), ("tri_begin", "<i4"), ("tri_count", "<i4"),
      ("color", "<f4", 3), ("coeff", "<f4"), ("ior", "<f4"), ("decay", "<f4", 3), ("sigma_s", "<f4", 3),
-     ("sigma_a", "<f4", 3), ("g", "<f4")], align=False)
-assert OBJECT_DTYPE.itemsize == 80
+     ("sigma_a", "<f4", 3), ("g", "<f4"), ("color2", "<f4", 3)], align=False)
+assert OBJECT_DTYPE.itemsize == 92
 
 
 class Camera(C.Structure):

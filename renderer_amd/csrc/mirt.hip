@@ -386,7 +386,7 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     for (int o = 0; o < s->n_objects; o++) {
         any_vn |= s->objects[o].has_vn != 0;
         int ty = s->objects[o].type;
-        if (ty < MIRT_OBJ_DIFFUSE || ty > MIRT_OBJ_VPM)
+        if (ty < MIRT_OBJ_DIFFUSE || ty > MIRT_OBJ_PHONG)
             return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: unknown object type");
         n_vpm += ty == MIRT_OBJ_VPM;
         if (s->objects[o].tri_begin < 0 || s->objects[o].tri_count < 0 ||
@@ -509,6 +509,7 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         d.pad = 0;
         for (int c = 0; c < 3; c++) {
             d.color[c] = m.color[c];
+            d.color2[c] = m.color2[c];
             d.decay[c] = m.decay[c];
         }
         d.coeff = m.coeff;

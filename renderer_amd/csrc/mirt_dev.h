@@ -63,6 +63,7 @@ struct DevObject {
     float sigma_s[3];  // homogeneous medium (SceneVPMObject.h:13-14): ds, dt = ds + da, HG g
     float sigma_t[3];
     float g;
+    float color2[3];   // MIRT_OBJ_PHONG: glossy colour (color = diffuse)
     float emit_pdf_a;  // emissive objects: weight / totalArea of the emission sampler (SceneObject.cpp:11-21,
                        // Scene.cpp:19-33), the area density PathTracerTest.cpp:38 uses for MIS
 };

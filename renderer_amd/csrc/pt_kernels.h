@@ -349,13 +349,24 @@ __device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const Dev
     r.emitted = false;
     r.random = true;
     r.nn = nn;
-    const f3 col = mk3(ob.color[0], ob.color[1], ob.color[2]);
-    if (ob.type == MIRT_OBJ_EMISSIVE) {
+    f3 col = mk3(ob.color[0], ob.color[1], ob.color[2]);
+    int type = ob.type;
+    if (type == MIRT_OBJ_PHONG) {
+        // SceneObject.cpp:366-373 with ScenePhongObject.h:16-19: one of {glossy, diffuse}, equal chance, one
+        // draw of the path's stream; the chance is not divided out
+        if (rng_float(key, ctr) < 0.5f) {
+            type = MIRT_OBJ_GLOSSY;
+            col = mk3(ob.color2[0], ob.color2[1], ob.color2[2]);
+        } else {
+            type = MIRT_OBJ_DIFFUSE;
+        }
+    }
+    if (type == MIRT_OBJ_EMISSIVE) {
         // SceneEmissiveObject.cpp:4-19: the path ends; radiance only from the front side
         r.color = dot3(d, nn) <= 0.f ? col : mk3(0, 0, 0);
         r.emitted = true;
         r.inside = -1;
-    } else if (ob.type == MIRT_OBJ_DIFFUSE) {
+    } else if (type == MIRT_OBJ_DIFFUSE) {
         if (dot3(d, nn) > 0.f) {  // DiffuseMaterial.cpp:35-44: back side passes through
             r.nd = d;
             r.color = mk3(1, 1, 1);
@@ -372,7 +383,7 @@ __device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const Dev
                 r.nd = dir;
             }
         }
-    } else if (ob.type == MIRT_OBJ_GLOSSY) {
+    } else if (type == MIRT_OBJ_GLOSSY) {
         f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
         Frame olf = frame_from_normal(refl);
         float dx = rng_float(key, ctr), dy = rng_float(key, ctr);
@@ -390,7 +401,7 @@ __device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const Dev
                 r.nd = dir;
             }
         }
-    } else if (ob.type == MIRT_OBJ_REFRACTIVE) {
+    } else if (type == MIRT_OBJ_REFRACTIVE) {
         r.random = false;
         if (ob.ior < 0.f) {  // mirror
             f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
@@ -475,13 +486,18 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
     if (hob.type == MIRT_OBJ_DIFFUSE) {
         if (sides) bsdf = div3(col, 3.14159265358979f);
         pdf = max3f(col) * cos_pdf(nn, odir, 1.f);  // DiffuseMaterial.cpp:78-86
-    } else if (hob.type == MIRT_OBJ_GLOSSY) {
+    } else if (hob.type == MIRT_OBJ_GLOSSY || hob.type == MIRT_OBJ_PHONG) {
+        const f3 gcol = hob.type == MIRT_OBJ_PHONG ? mk3(hob.color2[0], hob.color2[1], hob.color2[2]) : col;
         const f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
         if (sides) {
             const float rd = dot3(refl, odir);
-            if (rd > 0.f) bsdf = (col * powf(rd, hob.coeff)) * max3f(col);
+            if (rd > 0.f) bsdf = (gcol * powf(rd, hob.coeff)) * max3f(gcol);
         }
         pdf = cos_pdf(refl, odir, hob.coeff);  // GlossyMaterial.cpp:58-67
+        if (hob.type == MIRT_OBJ_PHONG) {  // SceneObject.cpp:227-248, 341-352: BSDFs add, densities average
+            bsdf = (mk3(0, 0, 0) + bsdf) + (sides ? div3(col, 3.14159265358979f) : mk3(0, 0, 0));
+            pdf = (pdf + max3f(col) * cos_pdf(nn, odir, 1.f)) / 2.f;
+        }
     }
     if (lum_y(bsdf) < 1e-7f) return false;
     const VnRec LV = sc.vns[lslot];

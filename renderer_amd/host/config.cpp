@@ -110,6 +110,17 @@ SceneObject* ConfigManager::generateSceneObject(XmlNode* nodeObj, XmlNode* nodeM
         m.type = MIRT_OBJ_GLOSSY;
         if (nodeMat->first_node("color")) setColor(m.color, readVec(nodeMat->first_node("color")->value()));
         if (nodeMat->first_node("coeff")) m.coeff = (float)atof(nodeMat->first_node("coeff")->value());
+    } else if (type == "Phong") {  // ConfigManager.cpp:48-58, ScenePhongObject.h:7-23
+        m.type = MIRT_OBJ_PHONG;
+        XmlNode* g = nodeMat->first_node("GlossyComponent");
+        XmlNode* df = nodeMat->first_node("DiffuseComponent");
+        if (!g || !df) throw std::runtime_error("ConfigManager: Phong material needs <GlossyComponent> and <DiffuseComponent>");
+        if (g->first_node("ColorTexture") || g->first_node("CoeffTexture") || df->first_node("Texture"))
+            throw std::runtime_error("ConfigManager: image / bump textures are outside this build (constant colours only)");
+        for (int c = 0; c < 3; c++) m.color2[c] = 1.f;  // GlossyMaterial / DiffuseMaterial default to white
+        if (g->first_node("color")) setColor(m.color2, readVec(g->first_node("color")->value()));
+        if (g->first_node("coeff")) m.coeff = (float)atof(g->first_node("coeff")->value());
+        if (df->first_node("color")) setColor(m.color, readVec(df->first_node("color")->value()));
     } else if (type == "Emissive") {
         m.type = MIRT_OBJ_EMISSIVE;
         if (!nodeMat->first_node("color")) throw std::runtime_error("ConfigManager: Emissive material needs <color>");

@@ -68,8 +68,9 @@ def _quad(p0, p1, p2, p3, normal):
     return v, f, np.tile(np.asarray(normal, np.float64), (4, 1))
 
 
-def _obj(kind, color=(1, 1, 1), coeff=0.0, ior=1.0, decay=(1, 1, 1), has_vn=1):
+def _obj(kind, color=(1, 1, 1), coeff=0.0, ior=1.0, decay=(1, 1, 1), has_vn=1, color2=(1, 1, 1)):
     o = np.zeros(1, ra.OBJECT_DTYPE)[0]
+    o["color2"] = color2
     o["type"] = kind
     o["has_vn"] = has_vn
     o["color"] = color
@@ -134,12 +135,12 @@ def _assemble(parts):
                 objects=np.array(objects, ra.OBJECT_DTYPE))
 
 
-def floor_and_light(albedo=0.6, emission=5.0):
+def floor_and_light(albedo=0.6, emission=5.0, floor=None):
     """a large diffuse floor at y = -1 under a unit-square emitter at y = 1 facing down; nothing else"""
     parts = [_quad((-0.5, 1, -0.5), (0.5, 1, -0.5), (0.5, 1, 0.5), (-0.5, 1, 0.5), (0, -1, 0)) +
              (_obj(ra.OBJ_EMISSIVE, (emission,) * 3),),
              _quad((-20, -1, -20), (20, -1, -20), (20, -1, 20), (-20, -1, 20), (0, 1, 0)) +
-             (_obj(ra.OBJ_DIFFUSE, (albedo,) * 3),)]
+             (floor if floor is not None else _obj(ra.OBJ_DIFFUSE, (albedo,) * 3),)]
     return _assemble(parts)
 
 

@@ -82,7 +82,7 @@ class OracleScene:
         self.tri_local = np.ascontiguousarray(raw["tri_local"], np.int32)
         self.tri_vn = None if raw.get("tri_vn") is None else np.ascontiguousarray(raw["tri_vn"], np.float32)
         self.objects = np.ascontiguousarray(raw["objects"])
-        assert self.objects.dtype.itemsize == 80
+        assert self.objects.dtype.itemsize == 92  # sizeof(OrcObject)
         self.h = lib().orc_scene_create(len(self.verts), _p(self.verts), len(self.tris), _p(self.tris),
                                         _p(self.tri_obj), _p(self.tri_local), _p(self.tri_vn),
                                         len(self.objects), _p(self.objects))

@@ -110,3 +110,25 @@ def test_pttest_through_host_surface(ra, cornell_oracle, tmp_path):
     assert rmse(img, c / 8) < 5e-3 and st.n_shadow_rays > 0
     assert os.path.exists(tmp_path / "cornell_pttest.pfm")
     s.close()
+
+
+def test_phong_object_parity(gpu, ra, orc):
+    """a Phong (glossy + diffuse) displaced sphere in the mesh scene: both integrators against the oracle"""
+    import meshgen
+    from test_gpu_pt import _parity as _pt_parity
+
+    m = meshgen.cornell_with_meshes(3)
+    m["objects"]["type"][6] = ra.OBJ_PHONG
+    m["objects"]["color"][6] = (0.5, 0.4, 0.2)
+    m["objects"]["color2"][6] = (0.4, 0.4, 0.4)
+    m["objects"]["coeff"][6] = 8.0
+    m["objects"]["type"][8] = ra.OBJ_DIFFUSE  # (the glass sphere amplifies ulp differences: test_gpu_pt.py)
+    m["objects"]["color"][8] = (0.6, 0.6, 0.6)
+    s = ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"], m["objects"], m["tri_vn"])
+    S = orc.OracleScene(s.raw())
+    gpu.upload(s.describe())
+    cam = ra.make_camera(96, 96, 65)
+    _pt_parity(gpu, S, cam, 16)
+    _parity(gpu, S, cam, 16)
+    S.close()
+    s.close()

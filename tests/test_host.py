@@ -255,3 +255,23 @@ def test_group_object_split(ra, tmp_path):
     scn.write_text(scn.read_text().replace('Name="zz"', 'Name="a"'))
     with pytest.raises(ra.MirtError, match="declared before its g line"):
         ra.HostScene.load_config(str(cfg))
+
+
+def test_phong_material_from_xml(ra, tmp_path):
+    """<type>Phong</type> with <GlossyComponent> / <DiffuseComponent> (ConfigManager.cpp:48-58)"""
+    (tmp_path / "t.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    (tmp_path / "s.xml").write_text("""<Scene Name="S"><Camera Name="c"><width>4</width><height>4</height>
+      <sightDist>4</sightDist><focus>(0, 0, 0)</focus><position>(0, 0, 3)</position><up>(0, 1, 0)</up></Camera>
+      <Object><filePath>t.obj</filePath><Material><type>Phong</type>
+      <GlossyComponent><color>(0.3, 0.2, 0.1)</color><coeff>9</coeff></GlossyComponent>
+      <DiffuseComponent><color>(0.4, 0.5, 0.6)</color></DiffuseComponent></Material></Object></Scene>""")
+    (tmp_path / "c.xml").write_text("<Config><Scene><path>s.xml</path><name>S</name><camera>c</camera></Scene>"
+                                    "<renderer>PT</renderer></Config>")
+    s = ra.HostScene.load_config(str(tmp_path / "c.xml"))
+    o = s.raw()["objects"][0]
+    assert o["type"] == ra.OBJ_PHONG and o["coeff"] == 9
+    assert np.allclose(o["color"], (0.4, 0.5, 0.6)) and np.allclose(o["color2"], (0.3, 0.2, 0.1))
+    s.close()
+    (tmp_path / "s.xml").write_text((tmp_path / "s.xml").read_text().replace("<DiffuseComponent>", "<X>").replace("</DiffuseComponent>", "</X>"))
+    with pytest.raises(ra.MirtError, match="GlossyComponent"):
+        ra.HostScene.load_config(str(tmp_path / "c.xml"))

@@ -365,3 +365,26 @@ def test_pttest_direct_light_known_answer(orc, ra):
     assert abs(got - expect) / expect < 0.05, (got, expect)
     S.close()
     s.close()
+
+
+def test_phong_known_answers(orc, ra):
+    """ScenePhongObject.h:7-23 + SceneObject.cpp:227-248, 341-373. A Phong floor whose glossy component is
+    black: a scatter picks the (dead) glossy material half the time and the choice is not divided out, so
+    the path tracer sees HALF the radiance of the plain diffuse floor; the light connection of PTtest
+    evaluates the SUM of the BSDFs, so its direct light (maxDepth 1) equals the diffuse floor's."""
+    import meshgen
+
+    cam = ra.make_camera(16, 16, 16, position=(0, 0.5, 2.5), focus=(0, -1, 0))
+    imgs = {}
+    for name, floor in (("diffuse", None),
+                        ("phong", meshgen._obj(ra.OBJ_PHONG, (0.6, 0.6, 0.6), coeff=5.0, color2=(0, 0, 0)))):
+        m = meshgen.floor_and_light(albedo=0.6, emission=5.0, floor=floor)
+        s = ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"], m["objects"], m["tri_vn"])
+        S = orc.OracleScene(s.raw())
+        pt, _ = S.render(cam, 6000, max_depth=3, seed=3, threads=8)
+        nee, _, _ = S.render_pttest(cam, 2000, max_depth=1, seed=3, threads=8)
+        imgs[name] = (pt[6:10, 6:10].mean() / 6000, nee[6:10, 6:10].mean() / 2000)
+        S.close()
+        s.close()
+    assert abs(imgs["phong"][0] / imgs["diffuse"][0] - 0.5) < 0.06, imgs
+    assert abs(imgs["phong"][1] / imgs["diffuse"][1] - 1.0) < 0.05, imgs
