@@ -276,14 +276,24 @@ static int validate_tree(const TreeView& s, int* depth_out, std::string* why) {
     return MIRT_OK;
 }
 
-// every node bound is 0 or in [2^-36, 2^60) (what the slab classifier's error model needs)
+// What the slab classifier's error model needs of a tree: every node bound finite and below 2^60, and
+// the tree's extent per axis (largest |coordinate| of its root box, which is what the absolute part of
+// the margin, RayPre::a_ray, is built from) zero or at least 2^-36. Individual bounds may be arbitrarily
+// small (a tessellated sphere leaves coordinates like 6e-17 where a cosine should be zero): the rounding
+// of the reference's quotients and products is relative to magnitudes that `extent` bounds, and where a
+// tiny operand underflows the absolute error is below 2^-149, i.e. below 2^-149 * 2^40 in t units, far
+// under a_ray >= 2^-20 * 2^-36 * 2^-40.
 static bool bounds_in_model(const TreeView& s) {
+    float extent[3] = {0.f, 0.f, 0.f};
     for (int i = 0; i < s.N; i++)
         for (int c = 0; c < 3; c++)
             for (float v : {s.mn[3 * i + c], s.mx[3 * i + c]}) {
                 float a = std::fabs(v);
-                if (!(a == 0.f || (a >= 1.4551915e-11f && a < 1.1529215e18f))) return false;  // also NaN/inf
+                if (!(a < 1.1529215e18f)) return false;  // also NaN/inf
+                if (i == 0) extent[c] = std::max(extent[c], a);
             }
+    for (int c = 0; c < 3; c++)
+        if (!(extent[c] == 0.f || extent[c] >= 1.4551915e-11f)) return false;
     return true;
 }
 

@@ -99,7 +99,7 @@ struct DevScene {
     const int* light_slot;     // slot of each light triangle
     int n_lights;
     float light_total_weight;  // SurfaceSampler::totalWeight
-    int fast_ok;          // every node bound is 0 or in [2^-36, 2^60): the slab classifier may be used
+    int fast_ok;          // node bounds finite, < 2^60, extent per axis 0 or >= 2^-36: the slab classifier may be used
 };
 
 struct f3 {

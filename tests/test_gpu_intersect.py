@@ -2,6 +2,7 @@
 Bar (BASELINE.json north_star): hit id equal on >= 99.99 % of rays, t within 1e-5 relative; the
 kernel is built to be bit-exact, so the tests also report and bound the exact-match rate."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -189,7 +190,13 @@ def test_classifier_audit(gpu, cornell, mesh20k, cornell_oracle, ra):
             if np.linalg.norm(verts[k][3:6]) > 0.5:
                 surf.append(verts[k][:6])
     surf = np.array(surf, np.float32)
-    for scene, inside in ((cornell, 2), (mesh20k, 8)):
+    # BallsInFog: a ball centred on z = 0 leaves coordinates like 1e-17 in node bounds (the classifier's
+    # model only asks the scene's extent to be >= 2^-36), and every ray starts inside the fog cube
+    fog = ra.HostScene.load_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "Data",
+                                                "Config_Fog128.xml"))
+    tiny = np.abs(fog.tree()["node_min"])
+    assert ((tiny > 0) & (tiny < 1e-12)).any()
+    for scene, inside in ((cornell, 2), (mesh20k, 8), (fog, 0)):
         gpu.upload(scene.describe())
         n = 1 << 21
         o, d, aux = meshgen.random_rays(n, 91, scene.n_objects, inside_obj=inside)
@@ -213,6 +220,7 @@ def test_classifier_audit(gpu, cornell, mesh20k, cornell_oracle, ra):
             assert a["ambiguous"] / a["box"] < 0.10, a  # even on this adversarial mix most boxes are proven
             # exact tests run = unproven boxes + every box of the axis-parallel rays (outside the model)
             assert a["ambiguous"] <= a["walks"] < 0.25 * a["box"], a
+    fog.close()
 
 
 def test_device_pointer_entry_and_streams(cornell_dev, cornell, cornell_oracle, ra):
