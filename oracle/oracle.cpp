@@ -451,6 +451,117 @@ float orderedIntersect(const OrcScene& S, const KRay& ray, const Condition& cond
     return bestSlot >= 0 ? best : -1;
 }
 
+// ---- the product's FAST path, restated (DESIGN.md "fast tree"): near-first pruned traversal of a tree
+// GIVEN by the caller whose leaves carry slot ranges of this scene's reference tree, entering every box a
+// generously inflated slab test cannot exclude; then the winner's chain of reference boxes (leaf up to the
+// root) is checked with the reference box test, and a ray whose chain fails is answered by the exact
+// ordered traversal of the reference tree instead. Counts every box / triangle test on the way.
+struct GivenTree {
+    int n;
+    const float* mn;
+    const float* mx;
+    const int32_t* right;
+    const int32_t* lbeg;
+    const int32_t* lend;
+    V3 lo(int i) const { return V3(mn[3 * i], mn[3 * i + 1], mn[3 * i + 2]); }
+    V3 hi(int i) const { return V3(mx[3 * i], mx[3 * i + 1], mx[3 * i + 2]); }
+};
+// conservative: false only when the ray clearly misses (slabs disjoint by a wide relative margin)
+BoxRes boxConservative(const V3& minC, const V3& maxC, const KRay& ray) {
+    BoxRes r;
+    double tn = -INFINITY, tf = INFINITY;
+    bool outside = false;
+    for (int a = 0; a < 3; a++) {
+        double o = ray.origin[a], d = ray.direction[a];
+        if (d == 0) {
+            if (o < (double)minC[a] - 1e-4 * (1 + std::fabs(o)) || o > (double)maxC[a] + 1e-4 * (1 + std::fabs(o))) outside = true;
+            continue;
+        }
+        double t0 = (minC[a] - o) / d, t1 = (maxC[a] - o) / d;
+        tn = std::max(tn, std::min(t0, t1));
+        tf = std::min(tf, std::max(t0, t1));
+    }
+    const double m = 1e-3 * (1 + std::fabs(tn) + std::fabs(tf));
+    r.hit = !outside && !(tn > tf + m) && !(tf < -m);
+    r.lb = (float)std::max(0.0, tn - m);
+    return r;
+}
+float fastIntersect(const OrcScene& S, const GivenTree& T, const std::vector<int>& refParent,
+                    const std::vector<int>& slotNode, const KRay& ray, const Condition& cond, int& slotOut,
+                    Counters& cnt) {
+    float best = -1;
+    int bestSlot = -1;
+    struct E {
+        int node;
+        float lb;
+    };
+    std::vector<E> stack;
+    cnt.box++;
+    bool alive = boxConservative(T.lo(0), T.hi(0), ray).hit;
+    int cur = 0;
+    while (alive) {
+        bool pop = false;
+        if (T.right[cur] < 0) {
+            int lb = T.lbeg[cur], le = T.lend[cur];
+            for (int s = lb; s < le; s++) {
+                cnt.tri++;
+                unsigned tid = (unsigned)S.slotTid[s];
+                float t = triIntersect(S, ray, tid, nullptr);
+                if (!(t >= 0)) continue;
+                bool wins = bestSlot < 0 || t < best || (t == best && bestSlot < lb);
+                if (wins && cond.legal(S, ray, tid, t)) {
+                    best = t;
+                    bestSlot = s;
+                }
+            }
+            pop = true;
+        } else {
+            int L = cur + 1, R = T.right[cur];
+            cnt.box += 2;
+            BoxRes bl = boxConservative(T.lo(L), T.hi(L), ray);
+            BoxRes br = boxConservative(T.lo(R), T.hi(R), ray);
+            bool hl = bl.hit && !pruned(bl.lb, bestSlot >= 0, best);
+            bool hr = br.hit && !pruned(br.lb, bestSlot >= 0, best);
+            if (hl && hr) {
+                if (bl.lb <= br.lb) {
+                    stack.push_back({R, br.lb});
+                    cur = L;
+                } else {
+                    stack.push_back({L, bl.lb});
+                    cur = R;
+                }
+            } else if (hl) {
+                cur = L;
+            } else if (hr) {
+                cur = R;
+            } else {
+                pop = true;
+            }
+        }
+        if (pop) {
+            bool found = false;
+            while (!stack.empty()) {
+                E e = stack.back();
+                stack.pop_back();
+                if (pruned(e.lb, bestSlot >= 0, best)) continue;
+                cur = e.node;
+                found = true;
+                break;
+            }
+            if (!found) break;
+        }
+    }
+    if (bestSlot >= 0) {  // the winner's chain of REFERENCE boxes, by the reference test
+        for (int node = slotNode[bestSlot]; node >= 0; node = refParent[node]) {
+            cnt.box++;
+            if (!(boxIntersect(S.fmin[node], S.fmax[node], ray) >= 0))
+                return orderedIntersect(S, ray, cond, slotOut, cnt);  // exact re-run
+        }
+    }
+    slotOut = bestSlot;
+    return bestSlot >= 0 ? best : -1;
+}
+
 // ---- path tracing ---------------------------------------------------------------------------------
 const int CAMERA_OBJ = -2;  // Camera is a SceneObject used as contactObject (Camera.cpp:25)
 
@@ -1450,6 +1561,33 @@ void orc_visibility(const OrcScene* s, const float* origins, const float* direct
         // MCRenderer.cpp:117: srInfo.dist<0 || (srInfo.dist - length >= -EPSILON)
         visible[i] = (dist < 0 || (dist - max_dist[i] >= -1e-5f)) ? 1 : 0;
     }
+}
+
+void orc_intersect_fast(const OrcScene* s, int32_t n_nodes, const float* node_min, const float* node_max,
+                        const int32_t* node_right, const int32_t* leaf_begin, const int32_t* leaf_end,
+                        const float* origins, const float* directions, const int32_t* aux, size_t n, int mode,
+                        float* t_out, int32_t* tid_out, uint64_t* n_box, uint64_t* n_tri) {
+    GivenTree T{n_nodes, node_min, node_max, node_right, leaf_begin, leaf_end};
+    const int N = (int)s->fright.size();
+    std::vector<int> parent(N, -1), slotNode(s->slotTid.size(), 0);
+    for (int i = 0; i < N; i++)
+        if (s->fright[i] >= 0) {
+            parent[i + 1] = i;
+            parent[s->fright[i]] = i;
+        } else {
+            for (int k = s->fbegin[i]; k < s->fend[i]; k++) slotNode[k] = i;
+        }
+    Counters cnt;
+    for (size_t i = 0; i < n; i++) {
+        KRay r = loadRay(origins, directions, n, i);
+        Condition c = makeCond(mode, aux ? aux[i] : 0);
+        int slot = -1;
+        float t = (s->root && n_nodes > 0) ? fastIntersect(*s, T, parent, slotNode, r, c, slot, cnt) : -1;
+        if (t_out) t_out[i] = t;
+        if (tid_out) tid_out[i] = slot >= 0 ? s->slotTid[slot] : -1;
+    }
+    if (n_box) *n_box = cnt.box;
+    if (n_tri) *n_tri = cnt.tri;
 }
 
 void orc_intersect_ref_counts(const OrcScene* s, const float* origins, const float* directions,

@@ -87,6 +87,14 @@ void orc_intersect_ordered(const OrcScene* s, const float* origins, const float*
                            const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
                            uint64_t* n_box, uint64_t* n_tri);
 
+/* restatement of the product's FAST path over a tree GIVEN by the caller (pre-order, left child = i+1,
+ * leaves carrying slot ranges of this scene's reference tree): conservative near-first traversal, then the
+ * winner's chain of reference boxes by the reference test, exact re-run when that fails. Hits + counts. */
+void orc_intersect_fast(const OrcScene* s, int32_t n_nodes, const float* node_min, const float* node_max,
+                        const int32_t* node_right, const int32_t* leaf_begin, const int32_t* leaf_end,
+                        const float* origins, const float* directions, const int32_t* aux, size_t n, int mode,
+                        float* t_out, int32_t* tid_out, uint64_t* n_box, uint64_t* n_tri);
+
 /* known-answer entry points for single functions */
 float orc_box_intersect(const float bmin[3], const float bmax[3], const float o[3],
                         const float d[3]); /* KDTree.cpp:34-52 */

@@ -52,7 +52,7 @@ class SceneDesc(C.Structure):
 
 # every symbol include/mirt.h and include/mirt_host.h declare (checked by the CPU tests)
 MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_scene", "mirt_intersect",
-                "mirt_intersect_dev", "mirt_visibility", "mirt_visibility_dev", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
+                "mirt_intersect_dev", "mirt_visibility", "mirt_visibility_dev", "mirt_fast_tree", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
                 "mirt_render_pt_dev", "mirt_render_pttest", "mirt_render_pttest_dev", "mirt_capture_rays_dev", "mirt_device_info"]
 MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
@@ -96,6 +96,7 @@ def lib():
         L.mirt_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_int, C.c_void_p]
         L.mirt_visibility_dev.argtypes = L.mirt_visibility.argtypes + [C.c_void_p]
+        L.mirt_fast_tree.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)] + [C.c_void_p] * 5
         L.mirt_intersect_count_dev.argtypes = L.mirt_intersect.argtypes + [C.POINTER(C.c_uint64),
                                                                           C.POINTER(C.c_uint64)]
         L.mirt_intersect_audit_dev.argtypes = L.mirt_intersect.argtypes + [C.POINTER(C.c_uint64 * 8)]
@@ -187,6 +188,19 @@ class HostScene:
         lib().mirth_get_raw(self.h, _ptr(out["verts"]), _ptr(out["tris"]), _ptr(out["tri_obj"]),
                             _ptr(out["tri_local"]), _ptr(out["tri_vn"]), _ptr(out["objects"]))
         return out
+
+    def fast_tree(self):
+        """mirt_fast_tree: the surface-area hierarchy over this scene's leaves (host only)."""
+        N = self.n_nodes
+        out = dict(node_min=np.empty((N, 3), np.float32), node_max=np.empty((N, 3), np.float32),
+                   node_right=np.empty(N, np.int32), leaf_begin=np.empty(N, np.int32), leaf_end=np.empty(N, np.int32))
+        n = C.c_int32()
+        d = self.describe()
+        rc = lib().mirt_fast_tree(C.byref(d), N, C.byref(n), _ptr(out["node_min"]), _ptr(out["node_max"]),
+                                  _ptr(out["node_right"]), _ptr(out["leaf_begin"]), _ptr(out["leaf_end"]))
+        if rc != 0:
+            raise MirtError("mirt_fast_tree failed (%d): %s" % (rc, lib().mirt_last_error(None).decode()))
+        return {k: v[:n.value] for k, v in out.items()}
 
     def tree(self):
         N, T = self.n_nodes, self.n_tris

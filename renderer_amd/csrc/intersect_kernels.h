@@ -41,6 +41,7 @@ namespace mirt {
 #define MIRT_LEAF_BATCH 8
 #endif
 constexpr uint32_t RAY_CHUNK = MIRT_RAY_CHUNK;  // rays a wave reserves per queue atomic
+constexpr int FAST_AMBIGUOUS_BUDGET = 16;  // k_intersect<FAST>: unproven boxes a ray may enter before it is handed to the exact kernel
 constexpr int LEAF_BATCH = MIRT_LEAF_BATCH;     // triangles a lane tests per leaf phase before the wave regroups
 
 struct Audit {
@@ -70,18 +71,28 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
 // closest hit, vis_out[i] = 1 unless some legal hit has t - limit[i] < -EPSILON (macros.h:5), which
 // is exactly "closest legal hit is nearer than the limit" because the rounded difference is
 // monotone in t. The traversal stops at the first such hit and never enters boxes beyond the limit.
-template <int MODE, bool COUNT, bool SLOT_OUT, bool ANYHIT = false>
+// FAST: walk the fast tree (DevScene.fpairs) instead of the reference tree. Every box decision only has
+// to be conservative there (a box is skipped only when the classifier PROVES the reference test
+// misses it; proven hits and unproven boxes are both entered), the result is written as (t, SLOT) and
+// k_verify decides whether it is the reference's answer. Rays outside the classifier's error model are
+// not traversed at all (k_verify sends them to the exact kernel).
+// ray_list != nullptr: the queue hands out positions of ray_list, which holds the ray indices (the
+// exact re-run of the rays k_verify rejected).
 #ifndef MIRT_WAVES_PER_EU
 #define MIRT_WAVES_PER_EU 5
 #endif
+template <int MODE, bool COUNT, bool SLOT_OUT, bool ANYHIT = false, bool FAST = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_WAVES_PER_EU, MIRT_WAVES_PER_EU)))
 k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ D,
             const int* __restrict__ aux, uint32_t n_direct, const uint32_t* __restrict__ n_ptr,
             uint32_t plane_stride, float* __restrict__ t_out,
             int* __restrict__ id_out, unsigned long long* __restrict__ counters,
             uint32_t* __restrict__ queue, uint32_t lds_levels, uint2* __restrict__ spill,
-            const float* __restrict__ limit = nullptr, unsigned char* __restrict__ vis_out = nullptr) {
+            const float* __restrict__ limit = nullptr, unsigned char* __restrict__ vis_out = nullptr,
+            const uint32_t* __restrict__ ray_list = nullptr) {
     extern __shared__ uint32_t lds[];
+    const PairRec* __restrict__ pairs = FAST ? sc.fpairs : sc.pairs;
+    const float4 root_lo = FAST ? sc.froot_lo : sc.root_lo, root_hi = FAST ? sc.froot_hi : sc.root_hi;
     // ray count: given, or (wavefront path tracer) left in device memory by the previous shade pass
     const uint32_t n = n_ptr ? min(*n_ptr, n_direct) : n_direct;
     const uint32_t bs = blockDim.x;
@@ -107,6 +118,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     float best = -1.f, thr = INF;  // thr: entry distances beyond it cannot beat the closest hit (prune())
     int best_slot = -1, sp = 0, link = 0;
     int leaf_pos = 0, leaf_end = 0;  // triangles still to test in the current leaf
+    int unproven = 0;                // FAST: boxes entered without proof so far
     float lim = 0.f;                 // ANYHIT: distance limit of this ray
     bool occluded = false;
     RayPre pre;
@@ -180,6 +192,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             const uint32_t rank = __popcll(need & lt_mask);
             if (!active && rank < take) {
                 idx = pool_next + rank;
+                if (ray_list) idx = ray_list[idx];
                 o = mk3(O[idx], O[plane_stride + idx], O[2 * plane_stride + idx]);
                 d = mk3(D[idx], D[plane_stride + idx], D[2 * plane_stride + idx]);
                 a = 0;
@@ -192,14 +205,19 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                     occluded = false;
                 }
                 best_slot = -1;
+                unproven = 0;
                 sp = 0;
                 has = false;
                 active = true;
                 pre = ray_prepare(sc, o, d);
                 pre2 = ray_pairs(o, pre);
                 float lb;
-                const int code = slab_classify(sc.root_lo, sc.root_hi, box_is_flat(sc.root_lo, sc.root_hi), o, pre, lb);
-                if (resolve(sc.root_lo, sc.root_hi, code, lb)) enter(__float_as_int(sc.root_lo.w));
+                const int code = slab_classify(root_lo, root_hi, box_is_flat(root_lo, root_hi), o, pre, lb);
+                if (FAST) {
+                    if (COUNT) au.box++;
+                    if (pre.fast && code != BOX_MISS) enter(__float_as_int(root_lo.w));
+                } else if (resolve(root_lo, root_hi, code, lb))
+                    enter(__float_as_int(root_lo.w));
             }
             pool_next += take;
         }
@@ -218,12 +236,25 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             } else if (!go) {
                 break;
             }
-            const PairRec P = sc.pairs[link];
+            const PairRec P = pairs[link];
             float lbl, lbr;
             const int cl = slab_classify_pair(P.la, P.lb, pre2, pre, lbl);
             const int cr = slab_classify_pair(P.ra, P.rb, pre2, pre, lbr);
             bool vl = cl == BOX_HIT, vr = cr == BOX_HIT;
-            if (COUNT || !pre.fast || cl == BOX_AMBIGUOUS || cr == BOX_AMBIGUOUS) {
+            if (FAST) {  // conservative: only a proven miss is skipped
+                vl = cl != BOX_MISS;
+                vr = cr != BOX_MISS;
+                if (COUNT) au.box += 2;
+                // A ray whose margin is wide (a nearly axis-parallel direction: |1/d| ~ 1e9) can prove
+                // almost no miss and would walk the whole tree: after FAST_AMBIGUOUS_BUDGET unproven
+                // boxes it is given up and left to the exact kernel (slot -2 tells k_verify).
+                unproven += (cl == BOX_AMBIGUOUS) + (cr == BOX_AMBIGUOUS);
+                if (unproven > FAST_AMBIGUOUS_BUDGET) {
+                    vl = vr = false;
+                    sp = 0;
+                    best_slot = -2;
+                }
+            } else if (COUNT || !pre.fast || cl == BOX_AMBIGUOUS || cr == BOX_AMBIGUOUS) {
                 vl = resolve(pair_lo(P.la, P.lb), pair_hi(P.la, P.lb), cl, lbl);
                 vr = resolve(pair_lo(P.ra, P.rb), pair_hi(P.ra, P.rb), cr, lbr);
             }
@@ -306,7 +337,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             }
         } else if (active && !has) {
             t_out[idx] = best_slot >= 0 ? best : -1.f;
-            if (SLOT_OUT)
+            if (SLOT_OUT || FAST)
                 id_out[idx] = best_slot;
             else
                 id_out[idx] = best_slot >= 0 ? __float_as_int(sc.vns[best_slot].n1.w) : -1;
@@ -332,6 +363,67 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             atomicAdd(&counters[3], au.bad);
             atomicAdd(&counters[4], au.walk);
         }
+    }
+}
+
+// Decides whether the (t, slot) k_intersect<FAST> left for a ray is the reference's answer. The fast
+// kernel returns argmin t over a SUPERSET S of the reference's candidate set A (triangles passing the
+// triangle test and the predicate whose leaf box and every ancestor box pass the reference box test):
+// its conservative box test never skips a box the reference would enter. So: a miss in S is a miss;
+// a winner whose whole chain of reference boxes (leaf up to the root) passes the reference test is in
+// A and is therefore A's winner too (same total order: t, then the slot tie rule). Anything else, and
+// every ray outside the classifier's error model, goes on the list the exact kernel re-runs.
+// SLOT_OUT false: a confirmed slot is replaced by its global triangle id. counters[0] += box tests.
+template <bool SLOT_OUT, bool COUNT>
+__global__ void __launch_bounds__(256)
+k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, uint32_t n_direct,
+         const uint32_t* __restrict__ n_ptr, uint32_t plane_stride, const float* __restrict__ t_out,
+         int* __restrict__ id_out, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count,
+         unsigned long long* __restrict__ counters) {
+    const uint32_t n = n_ptr ? min(*n_ptr, n_direct) : n_direct;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool redo = false;
+    unsigned long long boxes = 0;
+    if (i < n) {
+        const f3 o = mk3(O[i], O[plane_stride + i], O[2 * plane_stride + i]);
+        const f3 d = mk3(D[i], D[plane_stride + i], D[2 * plane_stride + i]);
+        const RayPre pre = ray_prepare(sc, o, d);
+        const int slot = id_out[i];
+        if (!pre.fast) {
+            redo = true;
+        } else if (slot == -2) {  // the fast kernel gave this ray up
+            redo = true;
+        } else if (slot >= 0) {
+            int node = sc.slot_node[slot];
+            while (node >= 0) {
+                const NodeRec N = sc.rnodes[node];
+                float lb;
+                const int code = slab_classify(N.lo, N.hi, __float_as_int(N.hi.w) != 0, o, pre, lb);
+                if (COUNT) boxes++;
+                if (code != BOX_HIT && !(code == BOX_AMBIGUOUS && box_test(N.lo, N.hi, o, d).hit)) {
+                    redo = true;
+                    break;
+                }
+                node = __float_as_int(N.lo.w);
+            }
+            if (!redo && !SLOT_OUT) id_out[i] = __float_as_int(sc.vns[slot].n1.w);
+        } else if (!SLOT_OUT) {
+            id_out[i] = -1;
+        }
+    }
+    // wave-aggregated append
+    const unsigned long long m = __ballot(redo);
+    if (m) {
+        const uint32_t lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(list_count, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (redo) list[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) boxes += __shfl_down(boxes, off);
+        if ((threadIdx.x & 63) == 0 && boxes) atomicAdd(&counters[0], boxes);
     }
 }
 

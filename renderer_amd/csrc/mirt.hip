@@ -35,6 +35,12 @@ struct MirtContext {
     bool has_media = false;    // scene holds a homogeneous medium (MIRT_OBJ_VPM)
     bool media_ready = true;   // ... and every such object came with its own tree
     VolRoot* d_vols = nullptr;
+    PairRec* d_fpairs = nullptr;    // fast tree (build_fast_tree) + what k_verify needs
+    NodeRec* d_rnodes = nullptr;
+    int* d_slot_node = nullptr;
+    bool fast_tree = false;
+    uint32_t* d_fb_list = nullptr;  // rays k_verify hands to the exact kernel
+    size_t fb_cap = 0;
     DevLight* d_lights = nullptr;   // emission sampler tables (PathTracerTest)
     float* d_light_area = nullptr;
     int* d_light_slot = nullptr;
@@ -167,6 +173,13 @@ static void free_scene(MirtContext* ctx) {
     ctx->d_spill = nullptr;
     hipFree(ctx->d_vols);
     ctx->d_vols = nullptr;
+    hipFree(ctx->d_fpairs);
+    hipFree(ctx->d_rnodes);
+    hipFree(ctx->d_slot_node);
+    ctx->d_fpairs = nullptr;
+    ctx->d_rnodes = nullptr;
+    ctx->d_slot_node = nullptr;
+    ctx->fast_tree = false;
     hipFree(ctx->d_lights);
     hipFree(ctx->d_light_area);
     hipFree(ctx->d_light_slot);
@@ -217,6 +230,7 @@ int mirt_destroy(MirtContext* ctx) {
     hipFree(ctx->d_wq2);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_queue);
+    hipFree(ctx->d_fb_list);
     if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -295,6 +309,133 @@ static bool bounds_in_model(const TreeView& s) {
     for (int c = 0; c < 3; c++)
         if (!(extent[c] == 0.f || extent[c] >= 1.4551915e-11f)) return false;
     return true;
+}
+
+// ---- the fast tree ---------------------------------------------------------------------------------
+// A second hierarchy over the REFERENCE tree's leaves (their slot ranges and their boxes, unchanged),
+// built here with a binned surface-area heuristic. The reference's median split on vertex coordinates
+// makes a ray walk several root-to-leaf chains of heavily overlapping boxes (112 box tests per ray on
+// the 1 M-triangle scene); grouping the same leaves by surface area roughly halves that. The traversal
+// kernel walks THIS tree with a conservative box test and so sees a superset of the leaves the
+// reference would reach; k_verify then proves the winner's chain of reference boxes with the
+// reference's own test (DESIGN.md "fast tree"). Output: a pre-order TreeView (left child = i + 1)
+// whose leaves carry reference leaf slot ranges.
+struct FastTree {
+    std::vector<float> mn, mx;
+    std::vector<int32_t> right, lbeg, lend;
+    int depth = 0;
+};
+
+static void build_fast_tree(const TreeView& ref, FastTree& ft) {
+    struct Leaf {
+        float mn[3], mx[3], c[3];
+        int b, e;
+    };
+    std::vector<Leaf> leaves;
+    for (int i = 0; i < ref.N; i++)
+        if (ref.right[i] < 0 && ref.lend[i] > ref.lbeg[i]) {
+            Leaf l;
+            for (int k = 0; k < 3; k++) {
+                l.mn[k] = ref.mn[3 * i + k];
+                l.mx[k] = ref.mx[3 * i + k];
+                l.c[k] = 0.5f * (l.mn[k] + l.mx[k]);
+            }
+            l.b = ref.lbeg[i];
+            l.e = ref.lend[i];
+            leaves.push_back(l);
+        }
+    if (leaves.empty()) return;
+    auto area = [](const float* mn, const float* mx) {
+        const double dx = (double)mx[0] - mn[0], dy = (double)mx[1] - mn[1], dz = (double)mx[2] - mn[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    };
+    const int BINS = 16;
+    // iterative pre-order construction: a node's right index is patched when its right child is emitted
+    struct Job {
+        int b, e, depth, parent;  // parent: node whose `right` this job fills (-1: left child or root)
+    };
+    std::vector<Job> st;
+    st.push_back({0, (int)leaves.size(), 0, -1});
+    while (!st.empty()) {
+        const Job j = st.back();
+        st.pop_back();
+        const int node = (int)ft.right.size();
+        if (j.parent >= 0) ft.right[j.parent] = node;
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int q = j.b; q < j.e; q++)
+            for (int k = 0; k < 3; k++) {
+                mn[k] = std::min(mn[k], leaves[q].mn[k]);
+                mx[k] = std::max(mx[k], leaves[q].mx[k]);
+                cmn[k] = std::min(cmn[k], leaves[q].c[k]);
+                cmx[k] = std::max(cmx[k], leaves[q].c[k]);
+            }
+        for (int k = 0; k < 3; k++) {
+            ft.mn.push_back(mn[k]);
+            ft.mx.push_back(mx[k]);
+        }
+        ft.right.push_back(-1);
+        ft.lbeg.push_back(-1);
+        ft.lend.push_back(-1);
+        ft.depth = std::max(ft.depth, j.depth);
+        const int n = j.e - j.b;
+        if (n == 1) {
+            ft.lbeg[node] = leaves[j.b].b;
+            ft.lend[node] = leaves[j.b].e;
+            continue;
+        }
+        int mid = -1;
+        if (j.depth < 40) {  // beyond that depth fall back to halving the range, which bounds the depth
+            double best = INFINITY;
+            int best_axis = -1, best_bin = -1;
+            for (int k = 0; k < 3; k++) {
+                const float ext = cmx[k] - cmn[k];
+                if (!(ext > 0.f)) continue;
+                int cnt[BINS] = {0};
+                float bmn[BINS][3], bmx[BINS][3];
+                for (int b = 0; b < BINS; b++)
+                    for (int c = 0; c < 3; c++) bmn[b][c] = INFINITY, bmx[b][c] = -INFINITY;
+                for (int q = j.b; q < j.e; q++) {
+                    int b = std::min(BINS - 1, (int)((leaves[q].c[k] - cmn[k]) / ext * BINS));
+                    cnt[b]++;
+                    for (int c = 0; c < 3; c++) {
+                        bmn[b][c] = std::min(bmn[b][c], leaves[q].mn[c]);
+                        bmx[b][c] = std::max(bmx[b][c], leaves[q].mx[c]);
+                    }
+                }
+                double rarea[BINS];
+                int rcnt[BINS];
+                float amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                int acc = 0;
+                for (int b = BINS - 1; b > 0; b--) {
+                    for (int c = 0; c < 3; c++) amn[c] = std::min(amn[c], bmn[b][c]), amx[c] = std::max(amx[c], bmx[b][c]);
+                    acc += cnt[b];
+                    rarea[b] = acc ? area(amn, amx) : 0.0;
+                    rcnt[b] = acc;
+                }
+                for (int c = 0; c < 3; c++) amn[c] = INFINITY, amx[c] = -INFINITY;
+                acc = 0;
+                for (int b = 0; b + 1 < BINS; b++) {
+                    for (int c = 0; c < 3; c++) amn[c] = std::min(amn[c], bmn[b][c]), amx[c] = std::max(amx[c], bmx[b][c]);
+                    acc += cnt[b];
+                    if (acc == 0 || rcnt[b + 1] == 0) continue;
+                    const double cost = area(amn, amx) * acc + rarea[b + 1] * rcnt[b + 1];
+                    if (cost < best) best = cost, best_axis = k, best_bin = b;
+                }
+            }
+            if (best_axis >= 0) {
+                const float ext = cmx[best_axis] - cmn[best_axis];
+                auto it = std::partition(leaves.begin() + j.b, leaves.begin() + j.e, [&](const Leaf& l) {
+                    return std::min(BINS - 1, (int)((l.c[best_axis] - cmn[best_axis]) / ext * BINS)) <= best_bin;
+                });
+                mid = (int)(it - leaves.begin());
+                if (mid == j.b || mid == j.e) mid = -1;
+            }
+        }
+        if (mid < 0) mid = j.b + n / 2;
+        st.push_back({mid, j.e, j.depth + 1, node});  // right child: emitted after the whole left subtree
+        st.push_back({j.b, mid, j.depth + 1, -1});
+    }
 }
 
 // Appends the tree's child-pair records (breadth-first over its inner nodes) to `pairs`; leaf
@@ -474,6 +615,47 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
             slot_base += s->objects[obj_trees[k].object].tri_count;
         }
     }
+    // fast tree over the reference leaves + the reference nodes with parent links for k_verify
+    std::vector<PairRec> fpairs;
+    float4 froot_lo = root_lo, froot_hi = root_hi;
+    std::vector<NodeRec> rnodes(N);
+    std::vector<int> slot_node(std::max(T, 1), 0);
+    bool use_fast = true;
+    if (const char* e = getenv("MIRT_FAST_TREE")) use_fast = atoi(e) != 0;  // A/B switch
+    {
+        std::vector<int> parent(N, -1);
+        for (int i = 0; i < N; i++)
+            if (s->node_right[i] >= 0) {
+                parent[i + 1] = i;
+                parent[s->node_right[i]] = i;
+            } else {
+                for (int k = s->node_leaf_begin[i]; k < s->node_leaf_end[i]; k++) slot_node[k] = i;
+            }
+        for (int i = 0; i < N; i++) {
+            const float* mn = s->node_min + 3 * i;
+            const float* mx = s->node_max + 3 * i;
+            const int flat = (mn[0] == mx[0]) | (mn[1] == mx[1]) | (mn[2] == mx[2]);
+            float fp, ff;
+            memcpy(&fp, &parent[i], 4);
+            memcpy(&ff, &flat, 4);
+            rnodes[i].lo = make_float4(mn[0], mn[1], mn[2], fp);
+            rnodes[i].hi = make_float4(mx[0], mx[1], mx[2], ff);
+        }
+        if (use_fast) {
+            FastTree ft;
+            build_fast_tree(main_tree, ft);
+            if (ft.right.empty()) {
+                use_fast = false;
+            } else {
+                const TreeView fv{(int)ft.right.size(), T, ft.mn.data(), ft.mx.data(), ft.right.data(), ft.lbeg.data(),
+                                  ft.lend.data()};
+                int fdepth = ft.depth;
+                append_pairs(fv, 0, fpairs, &froot_lo, &froot_hi, &fdepth);
+                depth = std::max(depth, fdepth);
+            }
+        }
+        if (fpairs.empty()) fpairs.push_back(PairRec{});
+    }
     if (depth > MIRT_MAX_TREE_DEPTH)
         return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: tree deeper than MIRT_MAX_TREE_DEPTH");
     const size_t TT = (size_t)T + (size_t)extra_slots;
@@ -588,6 +770,18 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         HIPCHK(ctx, hipMalloc(&ctx->d_vols, sizeof(VolRoot) * vols.size()));
         HIPCHK(ctx, hipMemcpy(ctx->d_vols, vols.data(), sizeof(VolRoot) * vols.size(), hipMemcpyHostToDevice));
     }
+    HIPCHK(ctx, hipMalloc(&ctx->d_fpairs, sizeof(PairRec) * fpairs.size()));
+    HIPCHK(ctx, hipMemcpy(ctx->d_fpairs, fpairs.data(), sizeof(PairRec) * fpairs.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc(&ctx->d_rnodes, sizeof(NodeRec) * rnodes.size()));
+    HIPCHK(ctx, hipMemcpy(ctx->d_rnodes, rnodes.data(), sizeof(NodeRec) * rnodes.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc(&ctx->d_slot_node, sizeof(int) * slot_node.size()));
+    HIPCHK(ctx, hipMemcpy(ctx->d_slot_node, slot_node.data(), sizeof(int) * slot_node.size(), hipMemcpyHostToDevice));
+    ctx->sc.fpairs = ctx->d_fpairs;
+    ctx->sc.froot_lo = froot_lo;
+    ctx->sc.froot_hi = froot_hi;
+    ctx->sc.rnodes = ctx->d_rnodes;
+    ctx->sc.slot_node = ctx->d_slot_node;
+    ctx->fast_tree = use_fast;
     ctx->sc.vols = ctx->d_vols;
     ctx->sc.n_vols = n_obj_trees;
     if (!lights.empty()) {
@@ -652,43 +846,75 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
 }  // extern "C"
 
 // ---- launches -------------------------------------------------------------------------------------
-template <int MODE, bool COUNT, bool SLOT_OUT>
+template <int MODE, bool COUNT, bool SLOT_OUT, bool FAST>
 static void launch_pair(MirtContext* ctx, hipStream_t st, dim3 grid, dim3 block, const float* O, const float* D,
                         const int* aux, uint32_t n, const uint32_t* n_ptr, uint32_t stride, float* t_out,
-                        int* id_out, uint32_t* queue) {
-    hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT>), grid, block, ctx->lds_main, st, ctx->sc, O, D, aux, n,
-                       n_ptr, stride, t_out, id_out, ctx->d_counters, queue, ctx->lds_levels, ctx->d_spill);
+                        int* id_out, uint32_t* queue, const uint32_t* ray_list) {
+    hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT, false, FAST>), grid, block, ctx->lds_main, st, ctx->sc, O, D,
+                       aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue, ctx->lds_levels, ctx->d_spill,
+                       (const float*)nullptr, (unsigned char*)nullptr, ray_list);
 }
 
-// n_ptr == nullptr: n rays, grid sized to n. n_ptr != nullptr: the count is read on the device
-// (at most n), grid sized to the chip; `queue` is the launch's own zeroed queue word.
-template <bool COUNT, bool SLOT_OUT>
-static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
-                            const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out,
-                            const uint32_t* n_ptr = nullptr, uint32_t* queue = nullptr) {
-    if (n == 0) return MIRT_OK;
-    const uint32_t want = (n + ctx->block - 1) / ctx->block;
-    dim3 block(ctx->block), grid(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks));
-    if (!queue) {
-        // the queue head starts at zero for every launch
-        queue = ctx->d_queue;
-        HIPCHK(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), st));
-    }
+template <bool COUNT, bool SLOT_OUT, bool FAST>
+static int launch_mode(MirtContext* ctx, hipStream_t st, dim3 grid, dim3 block, int mode, const float* O,
+                       const float* D, const int* aux, uint32_t n, const uint32_t* n_ptr, uint32_t stride,
+                       float* t_out, int* id_out, uint32_t* queue, const uint32_t* ray_list) {
     switch (mode) {
         case MIRT_MODE_UNCONDITIONAL:
-            launch_pair<MIRT_MODE_UNCONDITIONAL, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue);
+            launch_pair<MIRT_MODE_UNCONDITIONAL, COUNT, SLOT_OUT, FAST>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue, ray_list);
             break;
         case MIRT_MODE_LAST_TID:
-            launch_pair<MIRT_MODE_LAST_TID, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue);
+            launch_pair<MIRT_MODE_LAST_TID, COUNT, SLOT_OUT, FAST>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue, ray_list);
             break;
         case MIRT_MODE_NO_SELF:
-            launch_pair<MIRT_MODE_NO_SELF, COUNT, SLOT_OUT>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue);
+            launch_pair<MIRT_MODE_NO_SELF, COUNT, SLOT_OUT, FAST>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue, ray_list);
             break;
         default:
             return fail(ctx, MIRT_E_INVALID, "intersect: unknown mode");
     }
     HIPCHK(ctx, hipGetLastError());
     return MIRT_OK;
+}
+
+// Closest hit of n rays (n_ptr != nullptr: the count is read on the device, at most n). With the fast
+// tree: three launches, k_intersect<FAST> over the fast tree, k_verify (the winner's chain of reference
+// boxes, by the reference's test), and the exact kernel over the reference tree for the rays k_verify
+// listed (few: ~1e-5 of a batch, plus rays with zero / extreme components). `qwords`: three zeroed words
+// owned by this call (queue head of the fast launch, list length, queue head of the exact launch).
+// exact_only: the reference tree alone (the audit entry point, and scenes without a fast tree).
+template <bool COUNT, bool SLOT_OUT>
+static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
+                            const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out,
+                            const uint32_t* n_ptr = nullptr, uint32_t* qwords = nullptr, bool exact_only = false) {
+    if (n == 0) return MIRT_OK;
+    const uint32_t want = (n + ctx->block - 1) / ctx->block;
+    dim3 block(ctx->block), grid(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks));
+    if (!qwords) {
+        qwords = ctx->d_queue;
+        HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
+    }
+    // camera rays (mode 0) are coherent and measured faster on the reference tree alone (0.94 vs 1.07 ms
+    // for the 4 Mi Cornell batch): the fast path serves the predicate mode, where the rays are incoherent
+    if (exact_only || !ctx->fast_tree || mode != MIRT_MODE_NO_SELF)
+        return launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out,
+                                                   id_out, qwords, nullptr);
+    if (n > ctx->fb_cap) {  // (first use / a larger batch than any before: not on the timed path)
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(ctx->d_fb_list);
+        ctx->d_fb_list = nullptr;
+        ctx->fb_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_fb_list, (size_t)n * sizeof(uint32_t)));
+        ctx->fb_cap = n;
+    }
+    int rc = launch_mode<COUNT, SLOT_OUT, true>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out, id_out,
+                                                qwords, nullptr);
+    if (rc != MIRT_OK) return rc;
+    hipLaunchKernelGGL((k_verify<SLOT_OUT, COUNT>), dim3(want), dim3(ctx->block), 0, st, ctx->sc, O, D, n, n_ptr, stride,
+                       (const float*)t_out, id_out, ctx->d_fb_list, qwords + 1, ctx->d_counters);
+    HIPCHK(ctx, hipGetLastError());
+    return launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, qwords + 1, stride, t_out,
+                                               id_out, qwords + 2, ctx->d_fb_list);
 }
 
 // visibility variant: vis_out[i] = 1 unless a legal hit lies nearer than limit[i]
@@ -731,6 +957,37 @@ static int check_intersect_args(MirtContext* ctx, const float* o, const float* d
 
 extern "C" {
 
+int mirt_fast_tree(const MirtSceneDesc* s, int32_t capacity_nodes, int32_t* n_nodes_out, float* node_min,
+                   float* node_max, int32_t* node_right, int32_t* leaf_begin, int32_t* leaf_end) {
+    if (!s || !n_nodes_out || s->n_nodes <= 0 || s->n_tris < 0 || !s->node_min || !s->node_max || !s->node_right ||
+        !s->node_leaf_begin || !s->node_leaf_end)
+        return MIRT_E_INVALID;
+    const TreeView view{s->n_nodes, s->n_tris, s->node_min, s->node_max, s->node_right, s->node_leaf_begin,
+                        s->node_leaf_end};
+    int depth = 0;
+    std::string why;
+    if (validate_tree(view, &depth, &why) != MIRT_OK) {
+        g_create_err = "mirt_fast_tree: " + why;
+        return MIRT_E_INVALID;
+    }
+    FastTree ft;
+    build_fast_tree(view, ft);
+    const int32_t n = (int32_t)ft.right.size();
+    *n_nodes_out = n;
+    if (n > capacity_nodes) return MIRT_E_LIMIT;
+    if (n && (!node_min || !node_max || !node_right || !leaf_begin || !leaf_end)) return MIRT_E_INVALID;
+    for (int32_t i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) {
+            node_min[3 * i + c] = ft.mn[3 * i + c];
+            node_max[3 * i + c] = ft.mx[3 * i + c];
+        }
+        node_right[i] = ft.right[i];
+        leaf_begin[i] = ft.lbeg[i];
+        leaf_end[i] = ft.lend[i];
+    }
+    return MIRT_OK;
+}
+
 int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* directions,
                        const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
                        void* stream) {
@@ -753,7 +1010,8 @@ int mirt_intersect_audit_dev(MirtContext* ctx, const float* origins, const float
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
     rc = launch_intersect<true, false>(ctx, ctx->stream, mode, origins, directions, aux,
-                                       (uint32_t)n, (uint32_t)n, t_out, tid_out);
+                                       (uint32_t)n, (uint32_t)n, t_out, tid_out, nullptr, nullptr,
+                                       getenv("MIRT_AUDIT_FAST") == nullptr);
     if (rc != MIRT_OK) return rc;
     unsigned long long h[8];
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -766,13 +1024,22 @@ int mirt_intersect_count_dev(MirtContext* ctx, const float* origins, const float
                              const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
                              uint64_t* n_box_tests, uint64_t* n_tri_tests) {
     if (ctx && (!n_box_tests || !n_tri_tests)) return fail(ctx, MIRT_E_INVALID, "intersect_count: NULL counter");
-    uint64_t audit[8];
-    int rc = mirt_intersect_audit_dev(ctx, origins, directions, aux, n, mode, t_out, tid_out, audit);
-    if (rc == MIRT_OK) {
-        *n_box_tests = audit[0];
-        *n_tri_tests = audit[1];
-    }
-    return rc;
+    int rc = check_intersect_args(ctx, origins, directions, aux, n, mode, t_out, tid_out);
+    if (rc != MIRT_OK) return rc;
+    *n_box_tests = *n_tri_tests = 0;
+    if (n == 0) return MIRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    // the product's own path, instrumented: fast-tree traversal + chain verification + exact re-runs
+    rc = launch_intersect<true, false>(ctx, ctx->stream, mode, origins, directions, aux, (uint32_t)n, (uint32_t)n,
+                                       t_out, tid_out);
+    if (rc != MIRT_OK) return rc;
+    unsigned long long h[8];
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_box_tests = h[0];
+    *n_tri_tests = h[1];
+    return MIRT_OK;
 }
 
 int mirt_intersect(MirtContext* ctx, const float* origins, const float* directions, const int32_t* aux,
@@ -970,7 +1237,7 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
         ctx->d_cnt = ctx->d_wq = ctx->d_ns = ctx->d_wq2 = ctx->h_cnt = nullptr;
         ctx->cnt_cap = 0;
         HIPCHK(ctx, hipMalloc(&ctx->d_cnt, words * sizeof(uint32_t)));
-        HIPCHK(ctx, hipMalloc(&ctx->d_wq, words * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc(&ctx->d_wq, 3 * words * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc(&ctx->d_ns, words * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc(&ctx->d_wq2, words * sizeof(uint32_t)));
         HIPCHK(ctx, hipHostMalloc(&ctx->h_cnt, words * sizeof(uint32_t)));
@@ -982,7 +1249,7 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_L, 0, 3 * ctx->pb_cap * sizeof(float), st));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt, 0, words * sizeof(uint32_t), st));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_wq, 0, words * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_wq, 0, 3 * words * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_generate, dim3((P + B - 1) / B), dim3(B), 0, st, cam, P, s0, prm->seed, cur->o,
                        cur->d, cur->stride, *cur, nee ? 2 : 1);
     HIPCHK(ctx, hipGetLastError());
@@ -1049,7 +1316,7 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
             HIPCHK(ctx, hipMemcpyAsync(cap->aux + cap->count, cur->ids, m * sizeof(int), hipMemcpyDeviceToDevice, st));
             cap->count += m;
         }
-        rc = timed_intersect(MIRT_MODE_NO_SELF, cur, bound, n_out, ctx->d_wq + depth + 1);  // MCRenderer.cpp:193-197
+        rc = timed_intersect(MIRT_MODE_NO_SELF, cur, bound, n_out, ctx->d_wq + 3 * (depth + 1));  // MCRenderer.cpp:193-197
         if (rc != MIRT_OK) return rc;
     }
     if (rgb_sum) {

@@ -16,10 +16,9 @@
 namespace mirt {
 
 // ---- HBM layout ------------------------------------------------------------------------------
-// node record, 32 B, pre-order (left child = i+1):
-//   lo = (min.x, min.y, min.z, bits(c0))   hi = (max.x, max.y, max.z, bits(c1))
-//   inner: c0 = right child index (> 0), c1 = 0        leaf: c0 = ~leaf_begin (< 0), c1 = leaf_end
-struct NodeRec {  // (unused by the kernels since the pair layout; kept for tools)
+// reference-tree node record, 32 B, pre-order: what k_verify walks from a leaf up to the root
+//   lo = (min.x, min.y, min.z, bits(parent index, -1 for the root))   hi = (max.x, max.y, max.z, bits(flat))
+struct NodeRec {
     float4 lo, hi;
 };
 // traversal record, 64 B: the two children of one inner node, in BREADTH-FIRST order of the inner
@@ -94,6 +93,13 @@ struct DevScene {
     int n_vols;
     int n_nodes, n_tris, n_objects, depth;
     float bound[3];       // max |coordinate| of the root box per axis
+    // fast tree (mirt.hip build_fast_tree): child pairs of a surface-area hierarchy over the reference
+    // tree's leaves, walked by k_intersect<FAST>; rnodes / slot_node let k_verify prove the winner's
+    // chain of reference boxes afterwards
+    const PairRec* fpairs;
+    float4 froot_lo, froot_hi;
+    const NodeRec* rnodes;
+    const int* slot_node;      // reference leaf node of every slot of the scene tree
     const DevLight* lights;    // emission sampler (PathTracerTest's light connections)
     const float* light_area;   // running triangle areas per light object (SceneObject::areaValues)
     const int* light_slot;     // slot of each light triangle
@@ -242,7 +248,8 @@ __device__ __forceinline__ int slab_classify(const float4 lo, const float4 hi, b
     const bool on_flat = flat & (tn == tf);
     const bool ok_gap = (gap > M) | on_flat;
     // the face that decides the hit: the exit face, or (origin outside) the entry face as well
-    const float e = tn >= 0.f ? fmaxf(e_top, e_bot) : e_bot;
+    // (on a flat box the one face is entry and exit at once: it must be clear of the other axes' entries AND exits)
+    const float e = on_flat ? fminf(e_top, e_bot) : (tn >= 0.f ? fmaxf(e_top, e_bot) : e_bot);
     const bool hit = ok_gap & (tf >= 0.f) & (e > M);
     const bool miss = (tf < -M) | (fminf(fminf(-gap, e_top), e_bot) > M) | (on_flat & (tf < 0.f));
     return hit ? BOX_HIT : (miss ? BOX_MISS : BOX_AMBIGUOUS);
@@ -275,7 +282,8 @@ __device__ __forceinline__ int slab_classify_pair(const float4 a, const float4 b
     const bool flat = __float_as_int(b.w) != 0;
     const bool on_flat = flat & (tn == tf);
     const bool ok_gap = (gap > M) | on_flat;
-    const float e = tn >= 0.f ? fmaxf(e_top, e_bot) : e_bot;
+    // (on a flat box the one face is entry and exit at once: it must be clear of the other axes' entries AND exits)
+    const float e = on_flat ? fminf(e_top, e_bot) : (tn >= 0.f ? fmaxf(e_top, e_bot) : e_bot);
     const bool hit = ok_gap & (tf >= 0.f) & (e > M);
     const bool miss = (tf < -M) | (fminf(fminf(-gap, e_top), e_bot) > M) | (on_flat & (tf < 0.f));
     return hit ? BOX_HIT : (miss ? BOX_MISS : BOX_AMBIGUOUS);

@@ -6,8 +6,15 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import renderer_amd as ra
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-scene = ra.HostScene.load_config(os.path.join(ROOT, "Data", "Config_Glossy1024.xml"))
-cam = scene.camera(); dev = ra.Device(device=0); dev.upload(scene.describe())
+if os.environ.get("SCENE") == "mesh1m":
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import meshgen
+    scene = meshgen.mesh_scene(7); cam = ra.make_camera(1024, 1024, 700)
+elif os.environ.get("SCENE") == "fog":
+    scene = ra.HostScene.load_config(os.path.join(ROOT, "Data", "Config_Fog1024.xml")); cam = scene.camera()
+else:
+    scene = ra.HostScene.load_config(os.path.join(ROOT, "Data", "Config_Glossy1024.xml")); cam = scene.camera()
+dev = ra.Device(device=0); dev.upload(scene.describe())
 wh = cam.width * cam.height; n_pri = wh * 4; cap = 12 << 20
 po = torch.empty((3, n_pri), dtype=torch.float32, device="cuda"); pd = torch.empty_like(po)
 so = torch.empty((3, cap), dtype=torch.float32, device="cuda"); sd = torch.empty_like(so)

@@ -59,6 +59,9 @@ def lib():
                                      C.c_int, C.c_void_p, C.c_int]
         for f in ("orc_local_frame", "orc_to_world", "orc_face_normal", "orc_interp_normal", "orc_normalize"):
             getattr(L, f).restype = None
+        L.orc_intersect_fast.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_size_t, C.c_int, C.c_void_p,
+                                                                                       C.c_void_p, C.POINTER(C.c_uint64),
+                                                                                       C.POINTER(C.c_uint64)]
         L.orc_trace_path.restype = C.c_int32
         L.orc_trace_path.argtypes = [C.c_void_p, C.POINTER(OrcCamera), C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p]
@@ -121,6 +124,21 @@ class OracleScene:
         vis = np.empty(o.shape[1], np.uint8)
         lib().orc_visibility(self.h, _p(o), _p(d), _p(a), _p(m), o.shape[1], mode, _p(vis), threads)
         return vis
+
+    def intersect_fast(self, tree, o, d, aux=None, mode=0):
+        """restatement of the product's fast path over `tree` (renderer_amd.HostScene.fast_tree())"""
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        a = None if aux is None else np.ascontiguousarray(aux, np.int32)
+        n = o.shape[1]
+        t = np.empty(n, np.float32)
+        tid = np.empty(n, np.int32)
+        nb, nt = C.c_uint64(), C.c_uint64()
+        tr = {k: np.ascontiguousarray(v) for k, v in tree.items()}
+        lib().orc_intersect_fast(self.h, len(tr["node_right"]), _p(tr["node_min"]), _p(tr["node_max"]),
+                                 _p(tr["node_right"]), _p(tr["leaf_begin"]), _p(tr["leaf_end"]), _p(o), _p(d), _p(a), n,
+                                 mode, _p(t), _p(tid), C.byref(nb), C.byref(nt))
+        return t, tid, nb.value, nt.value
 
     def ref_counts(self, o, d, aux=None, mode=0):
         o = np.ascontiguousarray(o, np.float32)

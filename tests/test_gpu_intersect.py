@@ -154,10 +154,11 @@ def test_large_batch_properties(cornell_dev, cornell, ra):
 
 
 def test_counts_match_ordered_restatement(cornell_dev, cornell, cornell_oracle, ra):
-    """The instrumented kernel's box / triangle test counts agree with the CPU restatement of the
-    same traversal order (they feed the algorithmic-bytes figure of bench.py). Not bit-equal: the
-    kernel orders children by slab distances computed with per-ray reciprocals and enters the rare
-    boxes its classifier cannot prove, so a few visits differ."""
+    """The instrumented launches' box / triangle test counts agree with the CPU restatement of the same
+    traversal (they feed the algorithmic-bytes figure of bench.py): mode 0 walks the reference tree
+    near-first with pruning, mode 2 walks the fast tree, then the winner's chain of reference boxes. Not
+    bit-equal: the kernel orders children by slab distances computed with per-ray reciprocals, enters the
+    rare boxes its classifier cannot prove, and its conservative test differs in the last digits."""
     import torch
 
     n = 50000
@@ -166,14 +167,64 @@ def test_counts_match_ordered_restatement(cornell_dev, cornell, cornell_oracle, 
     tt = torch.empty(n, dtype=torch.float32, device="cuda")
     ti = torch.empty(n, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
+    ft = cornell.fast_tree()
     for mode in (0, 2):
         nb, nt = cornell_dev.intersect_count_dev(to.data_ptr(), do_.data_ptr(), ta.data_ptr(), n, mode,
                                                  tt.data_ptr(), ti.data_ptr())
-        t2, i2, cb, ct = cornell_oracle.intersect_ordered(o, d, aux, mode)
-        assert abs(nb - cb) / cb < 0.02 and abs(nt - ct) / ct < 0.02, (nb, cb, nt, ct)
+        if mode == 0:
+            t2, i2, cb, ct = cornell_oracle.intersect_ordered(o, d, aux, mode)
+        else:
+            t2, i2, cb, ct = cornell_oracle.intersect_fast(ft, o, d, aux, mode)
+        assert abs(nb - cb) / cb < 0.03 and abs(nt - ct) / ct < 0.03, (mode, nb, cb, nt, ct)
         assert np.array_equal(ti.cpu().numpy(), i2) and np.array_equal(tt.cpu().numpy(), t2)
         rb, rt = cornell_oracle.ref_counts(o[:, :5000], d[:, :5000], aux[:5000], mode)
         assert nb / n < rb / 5000 and nt / n < rt / 5000
+
+
+def _adversarial_rays(scene, n, seed):
+    """rays the fast path must hand over or verify carefully: aimed exactly at corners and edge midpoints
+    of node boxes (grazing: the reference box test can fail on an ancestor while the triangle is hit),
+    nearly axis-parallel (the classifier's margin is so wide that it proves nothing: the unproven-box
+    budget ends the fast traversal), exactly axis-parallel and zero-component origins (outside its model)"""
+    rng = np.random.default_rng(seed)
+    t = scene.tree()
+    k = rng.integers(0, len(t["node_min"]), n)
+    lo, hi = t["node_min"][k], t["node_max"][k]
+    pick = rng.integers(0, 3, (n, 3))  # 0 = min, 1 = max, 2 = middle, per axis
+    target = np.where(pick == 0, lo, np.where(pick == 1, hi, 0.5 * (lo + hi)))
+    o = rng.uniform(-0.95, 0.95, (n, 3))
+    d = target - o
+    q = n // 4
+    d[q:2 * q] = rng.normal(size=(q, 3)) * np.array([1.0, 1e-9, 1.0])   # nearly axis-parallel
+    d[2 * q:2 * q + q // 2, rng.integers(0, 3)] = 0.0                      # exactly axis-parallel
+    o[2 * q + q // 2:3 * q, 1] = 0.0                                        # zero origin component
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+    return np.ascontiguousarray(o.T, np.float32), np.ascontiguousarray(d.T, np.float32)
+
+
+def test_fast_path_fallbacks(gpu, cornell, cornell_oracle, mesh20k, mesh20k_oracle, ra, monkeypatch):
+    """k_intersect<FAST> + k_verify + exact re-run == the reference closest hit, bit for bit, on rays built
+    to make the verification fail or the fast traversal give up; and the whole fast path == the exact
+    kernel alone (MIRT_FAST_TREE=0) on a large batch."""
+    for scene, S, inside in ((cornell, cornell_oracle, 2), (mesh20k, mesh20k_oracle, 8)):
+        gpu.upload(scene.describe())
+        n = 200000
+        o, d = _adversarial_rays(scene, n, 7)
+        rng = np.random.default_rng(8)
+        aux = ra.pack_ids(rng.integers(-1, scene.n_objects, n), np.where(rng.random(n) < 0.8, -1, inside))
+        tg, ig = gpu.intersect(o, d, aux, ra.MODE_NO_SELF)
+        tc, ic = S.intersect(o, d, aux, ra.MODE_NO_SELF, threads=16)
+        assert np.array_equal(ig, ic) and np.array_equal(tg, tc)
+        assert (ic >= 0).mean() > 0.3
+        # large batch, fast path against the exact kernel alone
+        o2, d2, aux2 = meshgen.random_rays(1 << 21, 77, scene.n_objects, inside_obj=inside)
+        o2[:, :n], d2[:, :n] = o, d
+        t1, i1 = gpu.intersect(o2, d2, aux2, ra.MODE_NO_SELF)
+        monkeypatch.setenv("MIRT_FAST_TREE", "0")
+        gpu.upload(scene.describe())
+        monkeypatch.delenv("MIRT_FAST_TREE")
+        t0, i0 = gpu.intersect(o2, d2, aux2, ra.MODE_NO_SELF)
+        assert np.array_equal(i1, i0) and np.array_equal(t1, t0)
 
 
 def test_classifier_audit(gpu, cornell, mesh20k, cornell_oracle, ra):
@@ -221,6 +272,28 @@ def test_classifier_audit(gpu, cornell, mesh20k, cornell_oracle, ra):
             # exact tests run = unproven boxes + every box of the axis-parallel rays (outside the model)
             assert a["ambiguous"] <= a["walks"] < 0.25 * a["box"], a
     fog.close()
+
+
+def test_classifier_audit_adversarial(gpu, cornell, mesh20k, ra):
+    """The audit on rays aimed exactly at corners / edge midpoints of node boxes, where entry and exit
+    parameters of several axes coincide. (These found a hole in the first flat-box rule: a ray through the
+    CORNER of an axis-aligned wall's box has tn == tf on the flat axis and the same value as another axis'
+    exit; the face must be clear of the other axes' entries AND exits, not of either.)"""
+    import torch
+
+    for scene in (cornell, mesh20k):
+        gpu.upload(scene.describe())
+        n = 400000
+        o, d = _adversarial_rays(scene, n, 19)
+        aux = ra.pack_ids(np.full(n, -1), np.full(n, -1))
+        to, do_, ta = (torch.from_numpy(x).cuda() for x in (o, d, aux))
+        tt = torch.empty(n, dtype=torch.float32, device="cuda")
+        ti = torch.empty(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for mode in (0, 2):
+            a = gpu.intersect_audit_dev(to.data_ptr(), do_.data_ptr(), ta.data_ptr(), n, mode, tt.data_ptr(), ti.data_ptr())
+            assert a["mismatch"] == 0, a
+            assert a["ambiguous"] > 1000  # these rays do reach the unproven zone
 
 
 def test_device_pointer_entry_and_streams(cornell_dev, cornell, cornell_oracle, ra):

@@ -388,3 +388,36 @@ def test_phong_known_answers(orc, ra):
         s.close()
     assert abs(imgs["phong"][0] / imgs["diffuse"][0] - 0.5) < 0.06, imgs
     assert abs(imgs["phong"][1] / imgs["diffuse"][1] - 1.0) < 0.05, imgs
+
+
+def test_fast_tree_and_its_restatement(cornell, cornell_oracle, mesh20k, mesh20k_oracle):
+    """mirt_fast_tree (host-only): a binary hierarchy in which every leaf of the scene tree appears exactly
+    once with its slot range and box, and every node box is the union of its children's; the oracle's
+    restatement of the fast path over it (conservative traversal + reference-chain check + exact re-run)
+    returns exactly the reference closest hit, with fewer box tests than the reference tree needs."""
+    for scene, S, nobj, inside in ((cornell, cornell_oracle, 8, 2), (mesh20k, mesh20k_oracle, 9, 8)):
+        ref, ft = scene.tree(), scene.fast_tree()
+        right, lb, le = ft["node_right"], ft["leaf_begin"], ft["leaf_end"]
+        leaf = right < 0
+        ref_leaf = ref["node_right"] < 0
+        assert sorted(zip(lb[leaf].tolist(), le[leaf].tolist())) == sorted(
+            zip(ref["leaf_begin"][ref_leaf].tolist(), ref["leaf_end"][ref_leaf].tolist()))
+        key = {(b, e): i for i, (b, e) in enumerate(zip(ref["leaf_begin"].tolist(), ref["leaf_end"].tolist())) if ref_leaf[i]}
+        for i in np.nonzero(leaf)[0][:200]:
+            j = key[(int(lb[i]), int(le[i]))]
+            assert np.array_equal(ft["node_min"][i], ref["node_min"][j]) and np.array_equal(ft["node_max"][i], ref["node_max"][j])
+        inner = np.nonzero(~leaf)[0]
+        l, r = inner + 1, right[inner]
+        assert (r > l).all() and (r < len(right)).all()
+        assert np.array_equal(ft["node_min"][inner], np.minimum(ft["node_min"][l], ft["node_min"][r]))
+        assert np.array_equal(ft["node_max"][inner], np.maximum(ft["node_max"][l], ft["node_max"][r]))
+        assert np.array_equal(ft["node_min"][0], ref["node_min"][0]) and np.array_equal(ft["node_max"][0], ref["node_max"][0])
+        o, d, aux = meshgen.random_rays(20000, 15, nobj, inside_obj=inside)
+        d[:, :2000] *= np.array([[1.0], [1e-9], [1.0]], np.float32)  # nearly axis-parallel
+        d[1, 2000:3000] = 0
+        for mode, a in ((0, None), (2, aux)):
+            t, tid = S.intersect(o, d, a, mode, threads=8)
+            t2, tid2, nb, nt = S.intersect_fast(ft, o, d, a, mode)
+            assert np.array_equal(tid, tid2) and np.array_equal(t, t2)
+            rb, rt = S.ref_counts(o[:, :2000], d[:, :2000], None if a is None else a[:2000], mode)
+            assert nb / 20000 < 0.8 * rb / 2000
