@@ -107,7 +107,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
 
     Audit au;
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform ray pool
-    bool exhausted = false;
+    bool exhausted = false, first_chunk = true;
+    const uint32_t wave_id = blockIdx.x * (bs >> 6) + (threadIdx.x >> 6), total_waves = gridDim.x * (bs >> 6);
 
     // per-lane traversal state. `link` is the current child link: >= 0 pair index (inner node),
     // < 0 leaf (~link = begin | count << 24); has = false: nothing left to visit.
@@ -177,10 +178,16 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         const unsigned long long need = __ballot(!active);
         if (need) {
             if (pool_next == pool_end && !exhausted) {
-                uint32_t base = 0;
-                const int leader = __ffsll((long long)need) - 1;
-                if ((int)lane == leader) base = atomicAdd(queue, RAY_CHUNK);
-                base = __shfl(base, leader);
+                // a wave's FIRST chunk is its own (wave index), without touching the queue: a grid sized for
+                // an upper bound of the count (wavefront bounces, the exact re-run of a short list) would
+                // otherwise send thousands of atomics to one address just to learn there is nothing to do
+                uint32_t base = wave_id * RAY_CHUNK;
+                if (!first_chunk) {
+                    const int leader = __ffsll((long long)need) - 1;
+                    if ((int)lane == leader) base = atomicAdd(queue, RAY_CHUNK);
+                    base = __shfl(base, leader) + total_waves * RAY_CHUNK;
+                }
+                first_chunk = false;
                 if (base >= n) {
                     exhausted = true;
                 } else {
@@ -424,6 +431,112 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) boxes += __shfl_down(boxes, off);
         if ((threadIdx.x & 63) == 0 && boxes) atomicAdd(&counters[0], boxes);
+    }
+}
+
+// The exact re-run of the rays k_verify listed, one WAVE per ray. The list is short (~1e-5 of a batch)
+// but its rays are the slow ones: every box goes through the reference arithmetic (six IEEE divisions),
+// and with one lane per ray the launch lasts as long as the slowest ray's ~200 dependent steps (0.42 ms
+// measured on the 12.6 M ray Cornell batch for 157 rays). Here the 64 lanes test 64 boxes of ONE ray per
+// step: a stack of pair links in LDS, up to 32 pairs popped per step, lane l tests child (l & 1) of pair
+// (l >> 1), surviving inner children are pushed back, a lane whose child is a leaf tests its triangles.
+// No distance pruning: the answer is the plain definition, argmin over { legal triangle hits whose every
+// ancestor box passes box_test } in the order (t, later leaf link, earlier slot) of the header comment,
+// so the visit order is free. NO_SELF predicate only (the fast path serves that mode alone).
+// Stack bound: batch steps (pop k <= 32, push <= 2k) only while sp <= CAP - 192, single-pair depth-first
+// steps above that, which add at most depth + 1 (<= MIRT_MAX_TREE_DEPTH + 1) entries.
+constexpr int RERUN_STACK = 2048;
+template <bool SLOT_OUT>
+__global__ void __launch_bounds__(64)
+k_rerun(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, const int* __restrict__ aux,
+        uint32_t plane_stride, float* __restrict__ t_out, int* __restrict__ id_out,
+        const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
+    __shared__ int stack[RERUN_STACK];
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t count = *list_count;
+    for (uint32_t r = blockIdx.x; r < count; r += gridDim.x) {
+        const uint32_t idx = list[r];
+        const f3 o = mk3(O[idx], O[plane_stride + idx], O[2 * plane_stride + idx]);
+        const f3 d = mk3(D[idx], D[plane_stride + idx], D[2 * plane_stride + idx]);
+        const int a = aux[idx];
+        const int contact = unpack_contact(a), inside = unpack_inside(a);
+        float best = 0.f;
+        int best_slot = -1, best_leaf = -1;
+        int sp = 0;
+        int my_leaf = 0;  // leaf link this lane has to test (0: none; leaf links are negative)
+        if (box_test(sc.root_lo, sc.root_hi, o, d).hit) {
+            const int lk = __float_as_int(sc.root_lo.w);
+            if (lk >= 0) {
+                if (lane == 0) stack[0] = lk;
+                sp = 1;
+            } else if (lane == 0) {
+                my_leaf = lk;
+            }
+        }
+        __syncthreads();
+        for (;;) {
+            // ---- leaves found in the previous step (or the root leaf) --------------------------------
+            if (my_leaf < 0) {
+                const uint32_t v = ~(uint32_t)my_leaf;
+                const int beg = (int)(v & 0xFFFFFFu), end = beg + (int)(v >> 24);
+                for (int s = beg; s < end; s++) {
+                    const TriRec T = sc.tris[s];
+                    const float t = tri_test(T, o, d);
+                    if (!(t >= 0.f)) continue;
+                    if (!(best_slot < 0 || t < best || (t == best && best_leaf < beg))) continue;
+                    const VnRec V = sc.vns[s];
+                    const f3 nn = world_normal(T, V, __float_as_int(V.n2.w) != 0, o + d * t);
+                    if (!legal_noself(dot3(d, nn), __float_as_int(V.n0.w), contact, inside)) continue;
+                    best = t;
+                    best_slot = s;
+                    best_leaf = beg;
+                }
+                my_leaf = 0;
+            }
+            if (sp == 0) break;
+            // ---- one step: k pairs off the top of the stack, one child box per lane ---------------------
+            const int k = sp > RERUN_STACK - 192 ? 1 : min(32, sp);
+            const bool mine = (int)(lane >> 1) < k;
+            bool hit = false;
+            int lk = 0;
+            if (mine) {
+                const PairRec P = sc.pairs[stack[sp - 1 - (int)(lane >> 1)]];
+                const float4 ca = (lane & 1) ? P.ra : P.la, cb = (lane & 1) ? P.rb : P.lb;
+                hit = box_test(pair_lo(ca, cb), pair_hi(ca, cb), o, d).hit;
+                lk = __float_as_int(cb.z);
+            }
+            __syncthreads();  // every lane has read its stack entry
+            sp -= k;
+            const bool inner = hit && lk >= 0;
+            const unsigned long long m = __ballot(inner);
+            if (inner) {
+                const int pos = sp + __popcll(m & lt_mask);
+                if (pos < RERUN_STACK) stack[pos] = lk;  // (cannot fail: see the bound above)
+            }
+            sp = min(sp + (int)__popcll(m), RERUN_STACK);
+            if (hit && lk < 0) my_leaf = lk;
+            __syncthreads();
+        }
+        // ---- the wave's winner: smallest t, then the later leaf link, then the earlier slot ---------------
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ot = __shfl_xor(best, off);
+            const int os = __shfl_xor(best_slot, off), ol = __shfl_xor(best_leaf, off);
+            const bool take = os >= 0 && (best_slot < 0 || ot < best ||
+                                          (ot == best && (ol > best_leaf || (ol == best_leaf && os < best_slot))));
+            if (take) {
+                best = ot;
+                best_slot = os;
+                best_leaf = ol;
+            }
+        }
+        if (lane == 0) {
+            t_out[idx] = best_slot >= 0 ? best : -1.f;
+            if (SLOT_OUT)
+                id_out[idx] = best_slot;
+            else
+                id_out[idx] = best_slot >= 0 ? __float_as_int(sc.vns[best_slot].n1.w) : -1;
+        }
     }
 }
 

@@ -438,6 +438,38 @@ static void build_fast_tree(const TreeView& ref, FastTree& ft) {
     }
 }
 
+// A leaf link holds at most 127 triangles (LEAF_LINK_MAX); append_pairs hangs a larger reference leaf
+// [b, e) under synthetic pairs by halving the range. The kernels break distance ties by slot position:
+// the LATER leaf wins, inside one leaf link the EARLIER slot (KDTree.cpp:319-320, 305). The pieces of one
+// reference leaf must therefore rank the other way round, the piece with the leaf's first triangles
+// last: inside a reference leaf the earlier triangle wins (KDTree.cpp:305), and a triangle edge shared
+// across a seam between two pieces produces exactly such a tie. This returns slot -> position in the
+// reference's slot order with the pieces of every oversized leaf laid out in reverse.
+constexpr int LEAF_LINK_MAX = 127;
+static void leaf_pieces(int b, int e, std::vector<std::pair<int, int>>& out) {
+    if (e - b <= LEAF_LINK_MAX) {
+        out.push_back({b, e});
+        return;
+    }
+    const int mid = b + (e - b) / 2;
+    leaf_pieces(b, mid, out);
+    leaf_pieces(mid, e, out);
+}
+static std::vector<int> seam_order(const TreeView& v) {
+    std::vector<int> src(v.T);
+    for (int k = 0; k < v.T; k++) src[k] = k;
+    std::vector<std::pair<int, int>> pieces;
+    for (int i = 0; i < v.N; i++) {
+        if (v.right[i] >= 0 || v.lend[i] - v.lbeg[i] <= LEAF_LINK_MAX) continue;
+        pieces.clear();
+        leaf_pieces(v.lbeg[i], v.lend[i], pieces);
+        int pos = v.lbeg[i];
+        for (size_t j = pieces.size(); j-- > 0;)
+            for (int k = pieces[j].first; k < pieces[j].second; k++) src[k] = pos++;
+    }
+    return src;
+}
+
 // Appends the tree's child-pair records (breadth-first over its inner nodes) to `pairs`; leaf
 // links address slots slot_base + [begin, end). Returns the root's own record (box + link) and
 // adds the levels that oversized leaves needed to *depth.
@@ -463,10 +495,11 @@ static void append_pairs(const TreeView& s, int slot_base, std::vector<PairRec>&
     // A leaf link holds at most 127 triangles. The reference's build leaves larger leaves where no
     // split separates the triangles (a fan around one vertex). Such a leaf becomes a small subtree
     // of synthetic pairs whose children all carry the leaf's own box: the box test on them repeats
-    // the leaf's test bit for bit and slot order is kept, so the answer is unchanged.
+    // the leaf's test bit for bit, and seam_order() arranges the triangles inside the pieces so that the
+    // tie rule is unchanged too (same halving as leaf_pieces).
     int extra_depth = 0;
     std::function<int(int, int, int, int)> range_link = [&](int c, int b, int e, int level) -> int {
-        if (e - b <= 127) {
+        if (e - b <= LEAF_LINK_MAX) {
             extra_depth = std::max(extra_depth, level);
             return ~(int)((uint32_t)(slot_base + b) | ((uint32_t)(e - b) << 24));
         }
@@ -683,12 +716,14 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         memcpy(&fh, &hv, 4);
         vns[k].n2 = make_float4(vn ? vn[6] : 0.f, vn ? vn[7] : 0.f, vn ? vn[8] : 0.f, fh);
     };
-    for (int k = 0; k < T; k++) fill_slot((size_t)k, s->slot_tid[k]);
+    const std::vector<int> main_src = seam_order(main_tree);  // device slot -> position in the reference's slot order
+    for (int k = 0; k < T; k++) fill_slot((size_t)k, s->slot_tid[main_src[k]]);
     {
         size_t slot = (size_t)T;
         for (int k = 0; k < n_obj_trees; k++) {
             const MirtObject& ob = s->objects[obj_trees[k].object];
-            for (int q = 0; q < ob.tri_count; q++) fill_slot(slot++, ob.tri_begin + obj_trees[k].slot_tid[q]);
+            const std::vector<int> src = seam_order(obj_view[k]);
+            for (int q = 0; q < ob.tri_count; q++) fill_slot(slot++, ob.tri_begin + obj_trees[k].slot_tid[src[q]]);
         }
     }
     std::vector<DevObject> objs(s->n_objects);
@@ -723,7 +758,7 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     float light_total_weight = 0.f;
     {
         std::vector<int> slot_of(T, -1);
-        for (int k = 0; k < T; k++) slot_of[s->slot_tid[k]] = k;
+        for (int k = 0; k < T; k++) slot_of[s->slot_tid[main_src[k]]] = k;
         for (int o = 0; o < s->n_objects; o++) {
             const MirtObject& m = s->objects[o];
             if (m.type != MIRT_OBJ_EMISSIVE) continue;
@@ -913,8 +948,25 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
     hipLaunchKernelGGL((k_verify<SLOT_OUT, COUNT>), dim3(want), dim3(ctx->block), 0, st, ctx->sc, O, D, n, n_ptr, stride,
                        (const float*)t_out, id_out, ctx->d_fb_list, qwords + 1, ctx->d_counters);
     HIPCHK(ctx, hipGetLastError());
-    return launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, qwords + 1, stride, t_out,
-                                               id_out, qwords + 2, ctx->d_fb_list);
+    // the listed rays, by the reference arithmetic on the reference tree: one wave per ray (k_rerun); the
+    // instrumented call keeps the one-lane-per-ray kernel, whose counters the audit reads
+    static const bool rerun_wide = !getenv("MIRT_RERUN_WIDE") || atoi(getenv("MIRT_RERUN_WIDE")) != 0;  // A/B switch
+    if (!COUNT && rerun_wide) {
+        hipLaunchKernelGGL((k_rerun<SLOT_OUT>), dim3(std::min<uint32_t>(n, 1024)), dim3(64), 0, st, ctx->sc, O, D, aux,
+                           stride, t_out, id_out, (const uint32_t*)ctx->d_fb_list, (const uint32_t*)(qwords + 1));
+        HIPCHK(ctx, hipGetLastError());
+    } else {
+        rc = launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, qwords + 1, stride, t_out,
+                                                 id_out, qwords + 2, ctx->d_fb_list);
+    }
+    static const bool debug_list = getenv("MIRT_DEBUG_LIST") != nullptr;
+    if (debug_list && rc == MIRT_OK) {  // diagnostics only: synchronises the stream
+        uint32_t h[3] = {0, 0, 0};
+        hipStreamSynchronize(st);
+        hipMemcpy(h, qwords, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mirt] fast path: %u rays, %u re-run on the reference tree\n", n, h[1]);
+    }
+    return rc;
 }
 
 // visibility variant: vis_out[i] = 1 unless a legal hit lies nearer than limit[i]

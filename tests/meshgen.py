@@ -173,6 +173,19 @@ def fan_scene(n_fan=300, with_wall=True):
                                     np.concatenate(tri_obj), np.array(objects, ra.OBJECT_DTYPE), None)
 
 
+def flat_fan_scene(n_fan=300):
+    """A fan in the plane z = 0.25 around an apex that is its minimum corner (one leaf of n_fan triangles,
+    like fan_scene), with ring vertices k/512 on a straight line: every coordinate and every product in
+    the edge tests of a ray aimed at the middle of a spoke is exact, so such a ray hits BOTH triangles
+    sharing the spoke at the same t and the tie rule decides (KDTree.cpp:305: the earlier triangle)."""
+    k = np.arange(n_fan + 1, dtype=np.float64)
+    ring = np.stack([k / 512.0, (n_fan - k) / 512.0, np.full(n_fan + 1, 0.25)], axis=1)
+    v = np.concatenate([np.array([[0.0, 0.0, 0.25]]), ring])
+    f = np.stack([np.zeros(n_fan, np.int64), np.arange(1, n_fan + 1), np.arange(2, n_fan + 2)], axis=1)
+    objects = np.array([_obj(ra.OBJ_DIFFUSE, (0.7, 0.7, 0.3), has_vn=0)], ra.OBJECT_DTYPE)
+    return ra.HostScene.from_arrays(v.astype(np.float32), f.astype(np.uint32), np.zeros(n_fan, np.int32), objects, None)
+
+
 def _box(h, center=(0, 0, 0)):
     """axis-aligned cube of half-size h: 12 triangles, outward face normals"""
     cx, cy, cz = center

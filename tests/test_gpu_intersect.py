@@ -115,6 +115,40 @@ def test_oversized_leaf(gpu, ra, orc, with_wall):
     s.close()
 
 
+def test_oversized_leaf_seam_ties(gpu, ra, orc):
+    """Rays through the middle of every spoke of a flat fan hit the two triangles sharing the spoke at
+    the SAME t. All 300 lie in one reference leaf, where the earlier triangle wins (KDTree.cpp:305); the
+    upload cuts that leaf into pieces of <= 127, and between leaf links the kernels let the later one
+    win: the pieces are laid out in reverse for exactly this case (mirt.hip seam_order)."""
+    n_fan = 300
+    s = meshgen.flat_fan_scene(n_fan)
+    begin, end = s.tree()["leaf_begin"], s.tree()["leaf_end"]
+    assert (end - begin).max() >= n_fan
+    S = orc.OracleScene(s.raw())
+    gpu.upload(s.describe())
+    k = np.arange(1, n_fan, dtype=np.float64)
+    mid = np.stack([k / 1024.0, (n_fan - k) / 1024.0, np.full(len(k), 0.25)])  # half way along spoke k
+    os_, ds_ = [], []
+    for off in ((0, 0, 1), (0, 0, -1), (0.25, 0, 1), (0, -0.5, 0.5), (0.125, 0.25, -1), (0.3, -0.7, 0.9)):
+        off = np.array(off, np.float64)[:, None]
+        os_.append(mid + off)
+        ds_.append(np.broadcast_to(-off, mid.shape))
+    o = np.concatenate(os_, axis=1).astype(np.float32)
+    d = np.concatenate(ds_, axis=1).astype(np.float32)
+    aux = ra.pack_ids(np.full(o.shape[1], -1), np.full(o.shape[1], -1))
+    ties = 0
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_NO_SELF, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = S.intersect(o, d, a, mode, threads=16)
+        assert (ig == ic).all() and (tg == tc).all(), "seam ties mode %d: %d ids differ" % (mode, (ig != ic).sum())
+        # the straight-down rays do tie: the oracle's answer is the triangle BEFORE the spoke
+        straight = slice(0, n_fan - 1)
+        ties += int((ic[straight] == np.arange(0, n_fan - 1)).sum())
+    assert ties >= 2 * (n_fan - 1) - 4  # (nearly) every spoke was a real tie won by the earlier triangle
+    S.close()
+    s.close()
+
+
 def test_edge_cases(cornell_dev, cornell, cornell_oracle, ra):
     # empty batch
     t, i = cornell_dev.intersect(np.zeros((3, 0), np.float32), np.zeros((3, 0), np.float32))
