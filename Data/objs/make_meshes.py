@@ -94,4 +94,34 @@ with open(os.path.join(here, "spot_light2.obj"), "w") as f:
         b, n = nv + 4 * k, nn + 1 + k
         f.write("f %d//%d %d//%d %d//%d\n" % (b + 1, n, b + 2, n, b + 3, n))
         f.write("f %d//%d %d//%d %d//%d\n" % (b + 1, n, b + 3, n, b + 4, n))
+# plane_uv / ball_uv: the same meshes with texture coordinates (faces as v/vt/vn). The plane maps
+# (x, z) in [-1,1]^2 to (u, v) in [0,1]^2; the ball uses (longitude, latitude) with its own vt grid
+# (the seam and the poles need more vt than v, which .obj's separate indices allow)
+with open(os.path.join(here, "plane_uv.obj"), "w") as f:
+    f.write("# authored by Data/objs/make_meshes.py\n")
+    for v in pv: f.write("v %.9g %.9g %.9g\n" % v)
+    for v in pv: f.write("vt %.9g %.9g 0\n" % ((v[0] + 1) / 2, (v[2] + 1) / 2))
+    f.write("vn 0 1 0\n")
+    f.write("f 1/1/1 2/2/1 3/3/1\nf 1/1/1 3/3/1 4/4/1\n")
+with open(os.path.join(here, "ball_uv.obj"), "w") as f:
+    f.write("# authored by Data/objs/make_meshes.py\n")
+    for v in verts: f.write("v %.9g %.9g %.9g\n" % v)
+    for j in range(NV + 1):
+        for i in range(NU + 1): f.write("vt %.9g %.9g 0\n" % (i / NU, j / NV))
+    for v in verts: f.write("vn %.9g %.9g %.9g\n" % v)
+    def ring(idx):  # (j, i mod NU) of a 1-based vertex id
+        if idx == 1: return 0, None
+        if idx == len(verts): return NV, None
+        return 1 + (idx - 2) // NU, (idx - 2) % NU
+    for fc in faces:
+        ids = [c[0] for c in fc]
+        ji = [ring(a) for a in ids]
+        cols = [i for (_, i) in ji if i is not None]
+        wrap = max(cols) - min(cols) > NU // 2  # the face spans the seam: its column-0 corners use column NU
+        lo = min(c + NU if wrap and c == 0 else c for c in cols)  # the pole's column: the face's first
+        out = []
+        for a, (j, i) in zip(ids, ji):
+            col = lo if i is None else (i + NU if wrap and i == 0 else i)
+            out.append("%d/%d/%d" % (a, 1 + j * (NU + 1) + col, a))
+        f.write("f " + " ".join(out) + "\n")
 print("wrote plane.obj (2 tris), ball.obj (%d tris), cube.obj (%d tris)" % (len(faces), len(cf)))

@@ -90,6 +90,29 @@ typedef struct MirtObjTree {
     const int32_t* slot_tid;        /* [objects[object].tri_count]                            */
 } MirtObjTree;
 
+/* One texture (Texture.h:14-42): texels as Texture::loadFile (Texture.cpp:5-41) leaves them, row by row in
+ * file order; the two matrices row-major, applied as M * (x, y, z, 1) (Texture.cpp:45, 79).
+ * Lookup = Texture::getColor (Texture.cpp:43-94): bilinear, wrapping, texel centres at +0.5.       */
+typedef struct MirtTexture {
+    int32_t width, height;
+    int32_t channels;           /* 3: rgb texels ("PF"); 1: one float per texel ("Pf", or after toGrayScale) */
+    int32_t pad;
+    const float* texels;        /* [width*height*channels]                                          */
+    float coord_transform[16];  /* Texture::coordTransform                                          */
+    float color_transform[16];  /* Texture::colorTransform (colorScale folded in, Texture.cpp:157-161) */
+} MirtTexture;
+
+/* Which textures an object's materials read, -1 = none (the constant colour / coeff of MirtObject).
+ *   diffuse      DiffuseMaterial::tex       <Texture>       replaces color  (MIRT_OBJ_DIFFUSE, _PHONG)
+ *   glossy_color GlossyMaterial::colorTex   <ColorTexture>  replaces color (MIRT_OBJ_GLOSSY) / color2 (_PHONG)
+ *   glossy_coeff GlossyMaterial::coeffTex   <CoeffTexture>  replaces coeff (its .x)
+ * Texture coordinates come from tri_vt through SimpleShape::getTexCoord (SimpleShape.cpp:274-298).
+ * GlossyMaterial::scatter reads its two textures at getTexCoord(tid, (0,0,0)) (GlossyMaterial.cpp:11-12
+ * use outRay.origin before it is set at :17); the device does the same.                            */
+typedef struct MirtObjectTex {
+    int32_t diffuse, glossy_color, glossy_coeff, reserved;
+} MirtObjectTex;
+
 /* Flattened scene: what KDTree::serializeForGPU (KDTree.cpp:346-383) + Scene::buildKDTree
  * (Scene.cpp:248-275) hand to IntersectionGPU::loadKDTreeToShader (IntersectionGPU.cpp:243-255),
  * with integers kept as integers and the data the CPU hit predicate needs added.
@@ -120,6 +143,12 @@ typedef struct MirtSceneDesc {
     int32_t  n_obj_trees;           /* one per MIRT_OBJ_VPM object (required for rendering
                                        scenes that hold one; closest-hit queries do not use them) */
     const MirtObjTree* obj_trees;   /* [n_obj_trees]                                          */
+    /* textures (optional tail: absent in a shorter struct_size, or all zero) */
+    const float*   tri_vt;          /* [n_tris*9] corner texture coordinates (x y z each), by global
+                                       tid; NULL when no object has any                          */
+    int32_t  n_textures;
+    const MirtTexture* textures;    /* [n_textures]                                           */
+    const MirtObjectTex* object_tex; /* [n_objects] or NULL                                   */
 } MirtSceneDesc;
 
 /* Pinhole camera; fields as Camera.h:13-21 (sightDist is an unsigned int there). */

@@ -24,6 +24,11 @@ int mirth_load_config(const char* config_path, MirthScene** out);
 int mirth_scene_from_arrays(int32_t n_verts, const float* verts, int32_t n_tris, const uint32_t* tris,
                             const int32_t* tri_obj, const float* tri_vn, int32_t n_objects,
                             const MirtObject* objects, MirthScene** out);
+/* Gives a scene made from arrays its textures (copied): corner texture coordinates [T*9] by global triangle
+ * id (may be NULL), the textures, and which of them each object's materials read [n_objects]
+ * (MirtTexture / MirtObjectTex, include/mirt.h). A scene loaded from a config has them from its XML.   */
+int mirth_set_textures(MirthScene* s, const float* tri_vt, int32_t n_textures, const MirtTexture* textures,
+                       const MirtObjectTex* object_tex);
 void mirth_free(MirthScene* s);
 
 /* sizes: n_verts, n_tris, n_objects, n_nodes, tree depth */

@@ -114,6 +114,15 @@ struct OrcScene {
     std::vector<int32_t> triObj, triLocal;
     std::vector<V3> triVn;  // 3 per triangle, may be empty
     std::vector<OrcObject> objects;
+    // textures (orc_scene_set_textures): corner texture coordinates, 3 per triangle (empty: none)
+    struct Tex {
+        int width = 1, height = 1, channels = 3;
+        std::vector<float> texels;
+        float coordT[16], colorT[16];
+    };
+    std::vector<V3> triVt;
+    std::vector<Tex> textures;
+    std::vector<OrcObjectTex> objectTex;  // empty: no object reads a texture
     Node* root = nullptr;
     std::vector<Node*> objRoots;  // Scene::objKDTrees (Scene.cpp:287-320), volumetric objects only
     // flattened view (pre-order) used by the ordered-traversal restatement
@@ -248,6 +257,70 @@ V3 worldNormal(const OrcScene& S, unsigned tid, const V3& position) {
     const OrcObject& obj = S.objects[S.triObj[tid]];
     if (!obj.has_vn || S.triVn.empty()) return faceNormalOf(vps);
     return interpNormal(vps, &S.triVn[3 * (size_t)tid], position);
+}
+
+// SimpleShape::getTexCoord (SimpleShape.cpp:274-298): barycentric weights from world positions, like
+// the normal interpolation; (0,0,0) for a shape without texture coordinates
+V3 texCoord(const OrcScene& S, unsigned tid, const V3& position) {
+    if (S.triVt.empty()) return V3(0, 0, 0);
+    V3 vps[3];
+    for (int i = 0; i < 3; i++) vps[i] = S.verts[S.tris[tid].v[i]];
+    const V3* vts = &S.triVt[3 * (size_t)tid];
+    V3 b1 = vps[1] - vps[0];
+    V3 b2 = vps[2] - vps[0];
+    V3 v = position - vps[0];
+    float d12 = dot(b1, b2);
+    float l1 = length(b1);
+    float l2 = length(b2);
+    float u2 = (dot(v, b1) * d12 - dot(v, b2) * l1 * l1) / (d12 * d12 - l1 * l1 * l2 * l2);
+    float u1 = (dot(v, b1) - u2 * d12) / (l1 * l1);
+    return (1 - u1 - u2) * vts[0] + u1 * vts[1] + u2 * vts[2];
+}
+// matrix4 * vec4(v, w), xyz of the result (nvMatrix.h operator*: row . vector, accumulated left to right)
+V3 applyMat(const float m[16], const V3& v, float w) {
+    V3 r;
+    for (int i = 0; i < 3; i++) r[i] = v.x * m[4 * i] + v.y * m[4 * i + 1] + v.z * m[4 * i + 2] + w * m[4 * i + 3];
+    return r;
+}
+// Texture::getColor (Texture.cpp:43-94). The gray branch reads its fourth texel at (top, LEFT) as
+// the reference does (Texture.cpp:86).
+V3 textureColor(const OrcScene::Tex& T, const V3& coord) {
+    V3 tc = applyMat(T.coordT, coord, 1.f);
+    float u = tc.x * T.width - 0.5;
+    float v = tc.y * T.height - 0.5;
+    int left = (int)floor(u);
+    int right = left + 1;
+    int bottom = (int)floor(v);
+    int top = bottom + 1;
+    u -= left;
+    v -= bottom;
+    left %= T.width;
+    right %= T.width;
+    top %= T.height;
+    bottom %= T.height;
+    if (left < 0) left += T.width;
+    if (right < 0) right += T.width;
+    if (top < 0) top += T.height;
+    if (bottom < 0) bottom += T.height;
+    if (T.channels == 3) {
+        auto at = [&](int y, int x) {
+            const float* p = &T.texels[3 * ((size_t)y * T.width + x)];
+            return V3(p[0], p[1], p[2]);
+        };
+        V3 color(0, 0, 0);
+        color = color + at(bottom, left) * (1 - u) * (1 - v);
+        color = color + at(bottom, right) * u * (1 - v);
+        color = color + at(top, left) * (1 - u) * v;
+        color = color + at(top, right) * u * v;
+        return applyMat(T.colorT, color, 1.f);
+    }
+    auto at = [&](int y, int x) { return T.texels[(size_t)y * T.width + x]; };
+    float color = 0;
+    color += at(bottom, left) * (1 - u) * (1 - v);
+    color += at(bottom, right) * u * (1 - v);
+    color += at(top, left) * (1 - u) * v;
+    color += at(top, left) * u * v;
+    return applyMat(T.colorT, V3(color, color, color), 1.f);
 }
 
 // NoSelfIntersectionCondition.cpp:12-27
@@ -691,10 +764,34 @@ struct Tracer {
         return -1;
     }
 
+    // What the materials read at a point: the constant of the object, or its texture at
+    // getTexCoord(triangle, at) (DiffuseMaterial.cpp:23,83,99; GlossyMaterial.cpp:11-12,66,74,78)
+    const OrcScene::Tex* boundTex(int obj, int which) const {
+        if (S.objectTex.empty()) return nullptr;
+        const OrcObjectTex& b = S.objectTex[obj];
+        const int k = which == 0 ? b.diffuse : (which == 1 ? b.glossy_color : b.glossy_coeff);
+        return k >= 0 ? &S.textures[k] : nullptr;
+    }
+    V3 diffuseColor(int obj, unsigned localTri, const V3& at) const {
+        const OrcObject& o = S.objects[obj];
+        if (const OrcScene::Tex* T = boundTex(obj, 0)) return textureColor(*T, texCoord(S, globalTid(obj, localTri), at));
+        return V3(o.color[0], o.color[1], o.color[2]);
+    }
+    V3 glossyColor(int obj, unsigned localTri, const V3& at) const {
+        const OrcObject& o = S.objects[obj];
+        if (const OrcScene::Tex* T = boundTex(obj, 1)) return textureColor(*T, texCoord(S, globalTid(obj, localTri), at));
+        return o.type == ORC_PHONG ? V3(o.color2[0], o.color2[1], o.color2[2]) : V3(o.color[0], o.color[1], o.color[2]);
+    }
+    float glossyCoeff(int obj, unsigned localTri, const V3& at) const {
+        if (const OrcScene::Tex* T = boundTex(obj, 2)) return textureColor(*T, texCoord(S, globalTid(obj, localTri), at)).x;
+        return S.objects[obj].coeff;
+    }
+
     // DiffuseMaterial.cpp:4-76
     PRay scatterDiffuse(int object, const PRay& in, Stream& rng) const {
-        const OrcObject& o = S.objects[object];
-        return scatterDiffuse(object, V3(o.color[0], o.color[1], o.color[2]), in, rng);
+        // DiffuseMaterial.cpp:23: the texture at the hit point
+        const V3 at = in.origin + in.direction * in.intersectDist;
+        return scatterDiffuse(object, diffuseColor(in.intersectObject, in.intersectObjectTriangleID, at), in, rng);
     }
     PRay scatterDiffuse(int object, const V3& color, const PRay& in, Stream& rng) const {
         PRay out;
@@ -733,8 +830,11 @@ struct Tracer {
 
     // GlossyMaterial.cpp:4-56, GlossyBSDF.h:24-33
     PRay scatterGlossy(int object, const PRay& in, Stream& rng) const {
-        const OrcObject& o = S.objects[object];
-        return scatterGlossy(object, V3(o.color[0], o.color[1], o.color[2]), o.coeff, in, rng);
+        // GlossyMaterial.cpp:11-12 look the textures up at getTexCoord(tid, outRay.origin) BEFORE outRay.origin
+        // is set (:17): a default-constructed vec3f, (0,0,0) (nvVector.h:304)
+        const V3 at(0, 0, 0);
+        return scatterGlossy(object, glossyColor(in.intersectObject, in.intersectObjectTriangleID, at),
+                             glossyCoeff(in.intersectObject, in.intersectObjectTriangleID, at), in, rng);
     }
     PRay scatterGlossy(int object, const V3& color, float coeff, const PRay& in, Stream& rng) const {
         PRay out;
@@ -1087,10 +1187,8 @@ struct Tracer {
                 // SceneObject.cpp:366-373: materialList[rand() % 2], list = {glossy, diffuse}
                 // (ScenePhongObject.h:16-19); the choice costs one draw of the path's stream and its
                 // probability is NOT divided out
-                const OrcObject& o = S.objects[object];
-                if (rng.genFloat() < 0.5f)
-                    return scatterGlossy(object, V3(o.color2[0], o.color2[1], o.color2[2]), o.coeff, in, rng);
-                return scatterDiffuse(object, V3(o.color[0], o.color[1], o.color[2]), in, rng);
+                if (rng.genFloat() < 0.5f) return scatterGlossy(object, in, rng);
+                return scatterDiffuse(object, in, rng);
             }
             default: {
                 PRay dead;  // unsupported kind: terminate the path with zero weight
@@ -1343,8 +1441,11 @@ struct Tracer {
     V3 getBSDF(const PRay& inRay, const PRay& outRay) const {
         if (outRay.contactObject < 0) return V3(0, 0, 0);  // (no media here; the camera is never a vertex >= 1)
         const OrcObject& o = S.objects[outRay.contactObject];
-        V3 color(o.color[0], o.color[1], o.color[2]);
-        if (o.type == ORC_EMISSIVE) return dot(contactNormal(outRay), outRay.direction) < 0 ? V3(0, 0, 0) : color;
+        if (o.type == ORC_EMISSIVE)
+            return dot(contactNormal(outRay), outRay.direction) < 0 ? V3(0, 0, 0) : V3(o.color[0], o.color[1], o.color[2]);
+        // the materials' textures at the vertex itself (DiffuseMaterial.cpp:99, GlossyMaterial.cpp:74,78)
+        const V3 color = diffuseColor(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin);
+        const float gcoeff = glossyCoeff(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin);
         LocalFrame lf;
         lf.buildFromNormal(objNormal(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin));
         if (o.type == ORC_DIFFUSE) {
@@ -1356,14 +1457,15 @@ struct Tracer {
             V3 c(0, 0, 0);
             if (dot(lf.n, inRay.direction) <= 0 && dot(lf.n, outRay.direction) >= 0) {
                 V3 r2 = -dot(lf.n, inRay.direction) * lf.n * 2 + inRay.direction;
-                if (dot(r2, outRay.direction) > 0) c = gc * powf(dot(r2, outRay.direction), o.coeff);
+                if (dot(r2, outRay.direction) > 0) c = gc * powf(dot(r2, outRay.direction), gcoeff);
             }
             return p * c;
         };
-        if (o.type == ORC_GLOSSY) return glossy(color);
+        const V3 gcolor = glossyColor(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin);
+        if (o.type == ORC_GLOSSY) return glossy(gcolor);
         if (o.type == ORC_PHONG) {  // SceneObject.cpp:341-352: the materials' BSDFs add (glossy first)
             V3 bsdfColor(0, 0, 0);
-            bsdfColor = bsdfColor + glossy(V3(o.color2[0], o.color2[1], o.color2[2]));
+            bsdfColor = bsdfColor + glossy(gcolor);
             V3 dcol(0, 0, 0);
             if (dot(lf.n, inRay.direction) <= 0 && dot(lf.n, outRay.direction) >= 0) dcol = color / float(REF_PI);
             bsdfColor = bsdfColor + dcol;
@@ -1377,10 +1479,13 @@ struct Tracer {
     float directionSampleProbDensity(const PRay& inRay, const PRay& outRay) const {
         if (outRay.contactObject < 0) return 0;
         const OrcObject& o = S.objects[outRay.contactObject];
+        // DiffuseMaterial.cpp:83, GlossyMaterial.cpp:66: textures at the vertex
+        const V3 dcolor = diffuseColor(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin);
+        const float gcoeff = glossyCoeff(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin);
         if (o.type == ORC_DIFFUSE) {
             LocalFrame lf;
             lf.buildFromNormal(objNormal(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin));
-            float p = std::max(o.color[0], std::max(o.color[1], o.color[2]));
+            float p = std::max(dcolor.x, std::max(dcolor.y, dcolor.z));
             return p * cosPdf(lf, outRay.direction, 1.f);
         }
         if (o.type == ORC_GLOSSY) {
@@ -1388,7 +1493,7 @@ struct Tracer {
             V3 normal = contactNormal(outRay);
             V3 reflDir = -dot(normal, inRay.direction) * normal * 2 + inRay.direction;
             lf.buildFromNormal(reflDir);
-            return cosPdf(lf, outRay.direction, o.coeff);
+            return cosPdf(lf, outRay.direction, gcoeff);
         }
         if (o.type == ORC_REFRACTIVE) return 1;
         if (o.type == ORC_PHONG) {  // SceneObject.cpp:239-245: the mean of the materials' densities
@@ -1398,12 +1503,12 @@ struct Tracer {
                 V3 normal = contactNormal(outRay);
                 V3 reflDir = -dot(normal, inRay.direction) * normal * 2 + inRay.direction;
                 lf.buildFromNormal(reflDir);
-                prob += cosPdf(lf, outRay.direction, o.coeff);
+                prob += cosPdf(lf, outRay.direction, gcoeff);
             }
             {
                 LocalFrame lf;
                 lf.buildFromNormal(objNormal(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin));
-                float p = std::max(o.color[0], std::max(o.color[1], o.color[2]));
+                float p = std::max(dcolor.x, std::max(dcolor.y, dcolor.z));
                 prob += p * cosPdf(lf, outRay.direction, 1.f);
             }
             return prob / 2;
@@ -1499,6 +1604,38 @@ OrcScene* orc_scene_create(int32_t n_verts, const float* verts, int32_t n_tris, 
         S->objRoots[oi] = r;
     }
     return S;
+}
+
+void orc_scene_set_textures(OrcScene* S, const float* tri_vt, int32_t n_textures, const OrcTexture* textures,
+                            const OrcObjectTex* object_tex) {
+    S->triVt.clear();
+    if (tri_vt) {
+        S->triVt.resize(3 * S->tris.size());
+        for (size_t i = 0; i < S->triVt.size(); i++) S->triVt[i] = V3(tri_vt[3 * i], tri_vt[3 * i + 1], tri_vt[3 * i + 2]);
+    }
+    S->textures.assign(n_textures, OrcScene::Tex());
+    for (int k = 0; k < n_textures; k++) {
+        OrcScene::Tex& T = S->textures[k];
+        T.width = textures[k].width, T.height = textures[k].height, T.channels = textures[k].channels;
+        T.texels.assign(textures[k].texels, textures[k].texels + (size_t)T.width * T.height * T.channels);
+        memcpy(T.coordT, textures[k].coord_transform, sizeof T.coordT);
+        memcpy(T.colorT, textures[k].color_transform, sizeof T.colorT);
+    }
+    S->objectTex.clear();
+    if (object_tex && n_textures > 0) S->objectTex.assign(object_tex, object_tex + S->objects.size());
+}
+void orc_texture_color(const OrcTexture* tex, const float coord[3], float out[3]) {
+    OrcScene::Tex T;
+    T.width = tex->width, T.height = tex->height, T.channels = tex->channels;
+    T.texels.assign(tex->texels, tex->texels + (size_t)T.width * T.height * T.channels);
+    memcpy(T.coordT, tex->coord_transform, sizeof T.coordT);
+    memcpy(T.colorT, tex->color_transform, sizeof T.colorT);
+    const V3 c = textureColor(T, V3(coord[0], coord[1], coord[2]));
+    out[0] = c.x, out[1] = c.y, out[2] = c.z;
+}
+void orc_tex_coord(const OrcScene* s, int32_t tid, const float pos[3], float out[3]) {
+    const V3 c = texCoord(*s, (unsigned)tid, V3(pos[0], pos[1], pos[2]));
+    out[0] = c.x, out[1] = c.y, out[2] = c.z;
 }
 
 void orc_scene_destroy(OrcScene* s) {

@@ -45,6 +45,18 @@ typedef struct OrcObject {
     float color2[3]; /* ORC_PHONG: glossy colour (color = diffuse) */
 } OrcObject;
 
+/* Texture.h:14-42 as data: same layout as MirtTexture (include/mirt.h) */
+typedef struct OrcTexture {
+    int32_t width, height, channels, pad; /* channels 3 (rgb) or 1 (gray) */
+    const float* texels;
+    float coord_transform[16]; /* row-major */
+    float color_transform[16];
+} OrcTexture;
+/* which textures an object's materials read (-1: the constant of OrcObject); same layout as MirtObjectTex */
+typedef struct OrcObjectTex {
+    int32_t diffuse, glossy_color, glossy_coeff, reserved;
+} OrcObjectTex;
+
 typedef struct OrcCamera {
     int32_t width, height;
     uint32_t sight_dist;
@@ -59,6 +71,13 @@ OrcScene* orc_scene_create(int32_t n_verts, const float* verts, int32_t n_tris,
                            const float* tri_vn /* [T*9] or NULL */, int32_t n_objects,
                            const OrcObject* objects);
 void orc_scene_destroy(OrcScene* s);
+/* Attaches texture coordinates (tri_vt: [n_tris*9], 3 corners x (x y z), by global tid; may be NULL) and
+ * textures (texels are copied) to a scene; object_tex: [n_objects].                                 */
+void orc_scene_set_textures(OrcScene* s, const float* tri_vt, int32_t n_textures, const OrcTexture* textures,
+                            const OrcObjectTex* object_tex);
+/* Texture::getColor (Texture.cpp:43-94) and SimpleShape::getTexCoord (SimpleShape.cpp:274-298) */
+void orc_texture_color(const OrcTexture* tex, const float coord[3], float out[3]);
+void orc_tex_coord(const OrcScene* s, int32_t tid, const float pos[3], float out[3]);
 
 /* tree facts + pre-order flatten (KDTree.cpp:346-383) */
 int32_t orc_tree_num_nodes(const OrcScene* s);

@@ -47,14 +47,48 @@ class SceneDesc(C.Structure):
                 ("node_leaf_end", C.c_void_p), ("n_tris", C.c_int32), ("slot_tid", C.c_void_p),
                 ("tri_pos", C.c_void_p), ("tri_obj", C.c_void_p), ("tri_local", C.c_void_p),
                 ("tri_vn", C.c_void_p), ("n_objects", C.c_int32), ("objects", C.c_void_p),
-                ("n_obj_trees", C.c_int32), ("obj_trees", C.c_void_p)]
+                ("n_obj_trees", C.c_int32), ("obj_trees", C.c_void_p),
+                ("tri_vt", C.c_void_p), ("n_textures", C.c_int32), ("textures", C.c_void_p),
+                ("object_tex", C.c_void_p)]
+
+
+class Texture(C.Structure):
+    """MirtTexture (include/mirt.h)"""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("pad", C.c_int32),
+                ("texels", C.c_void_p), ("coord_transform", C.c_float * 16), ("color_transform", C.c_float * 16)]
+
+
+# MirtObjectTex: which texture (index, -1 none) each of an object's materials reads
+OBJECT_TEX_DTYPE = np.dtype([("diffuse", "<i4"), ("glossy_color", "<i4"), ("glossy_coeff", "<i4"), ("reserved", "<i4")])
+
+
+def make_texture(texels, coord_transform=None, color_transform=None):
+    """A texture as the Python side passes it around: texels (H, W, 3) rgb or (H, W) gray, row 0 first in
+    memory (the file order of Texture::loadFile), 4x4 row-major transforms (identity by default)."""
+    t = np.ascontiguousarray(texels, np.float32)
+    assert t.ndim == 2 or (t.ndim == 3 and t.shape[2] == 3)
+    eye = np.eye(4, dtype=np.float32)
+    return dict(texels=t, coord=eye if coord_transform is None else np.ascontiguousarray(coord_transform, np.float32),
+                color=eye if color_transform is None else np.ascontiguousarray(color_transform, np.float32))
+
+
+def texture_structs(textures):
+    """ctypes array of Texture for a list of make_texture() dicts (the dicts keep the texels alive)."""
+    arr = (Texture * max(1, len(textures)))()
+    for k, t in enumerate(textures):
+        arr[k].height, arr[k].width = t["texels"].shape[:2]
+        arr[k].channels = 3 if t["texels"].ndim == 3 else 1
+        arr[k].texels = t["texels"].ctypes.data
+        arr[k].coord_transform[:] = [float(x) for x in np.asarray(t["coord"], np.float32).reshape(16)]
+        arr[k].color_transform[:] = [float(x) for x in np.asarray(t["color"], np.float32).reshape(16)]
+    return arr
 
 
 # every symbol include/mirt.h and include/mirt_host.h declare (checked by the CPU tests)
 MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_scene", "mirt_intersect",
                 "mirt_intersect_dev", "mirt_visibility", "mirt_visibility_dev", "mirt_fast_tree", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
                 "mirt_render_pt_dev", "mirt_render_pttest", "mirt_render_pttest_dev", "mirt_capture_rays_dev", "mirt_device_info"]
-MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_free",
+MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_set_textures", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
                  "mirth_describe", "mirth_upload", "mirth_render", "mirth_render_progressive", "mirth_fill_intersect", "mirth_test_visibility", "mirth_world_vertex", "mirth_normal_transform",
                  "mirth_shutdown",
@@ -114,6 +148,7 @@ def lib():
         L.mirth_scene_from_arrays.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
         L.mirth_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int32 * 5)]
+        L.mirth_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.mirth_get_raw.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.mirth_get_tree.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.mirth_get_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
@@ -174,6 +209,16 @@ class HostScene:
             raise MirtError(lib().mirth_last_error().decode())
         return HostScene(h)
 
+    def set_textures(self, tri_vt, textures, object_tex):
+        """tri_vt: (T, 9) corner texture coordinates or None; textures: list of make_texture() dicts;
+        object_tex: (n_objects,) OBJECT_TEX_DTYPE."""
+        vt = None if tri_vt is None else np.ascontiguousarray(tri_vt, np.float32).reshape(self.n_tris, 9)
+        ot = np.ascontiguousarray(object_tex, OBJECT_TEX_DTYPE)
+        assert len(ot) == self.n_objects
+        arr = texture_structs(textures)
+        if lib().mirth_set_textures(self.h, _ptr(vt), len(textures), C.cast(arr, C.c_void_p), _ptr(ot)) != 0:
+            raise MirtError(lib().mirth_last_error().decode())
+
     def close(self):
         if self.h:
             lib().mirth_free(self.h)
@@ -187,6 +232,24 @@ class HostScene:
                    tri_vn=np.empty((T, 9), np.float32), objects=np.empty(O, OBJECT_DTYPE))
         lib().mirth_get_raw(self.h, _ptr(out["verts"]), _ptr(out["tris"]), _ptr(out["tri_obj"]),
                             _ptr(out["tri_local"]), _ptr(out["tri_vn"]), _ptr(out["objects"]))
+        # textures, read through the descriptor (copies)
+        d = self.describe()
+        out["tri_vt"] = None
+        if d.tri_vt:
+            out["tri_vt"] = np.ctypeslib.as_array(C.cast(d.tri_vt, C.POINTER(C.c_float)), (T, 9)).copy()
+        out["textures"], out["object_tex"] = [], None
+        if d.n_textures > 0:
+            arr = C.cast(d.textures, C.POINTER(Texture))
+            for k in range(d.n_textures):
+                X = arr[k]
+                shape = (X.height, X.width, 3) if X.channels == 3 else (X.height, X.width)
+                tex = np.ctypeslib.as_array(C.cast(X.texels, C.POINTER(C.c_float)), shape).copy()
+                out["textures"].append(make_texture(tex, np.array(X.coord_transform[:], np.float32).reshape(4, 4),
+                                                    np.array(X.color_transform[:], np.float32).reshape(4, 4)))
+            if d.object_tex:
+                n = O * OBJECT_TEX_DTYPE.itemsize
+                buf = (C.c_char * n).from_address(d.object_tex)
+                out["object_tex"] = np.frombuffer(buf, OBJECT_TEX_DTYPE, O).copy()
         return out
 
     def fast_tree(self):

@@ -42,6 +42,9 @@ struct MirtContext {
     uint32_t* d_fb_list = nullptr;  // rays k_verify hands to the exact kernel
     size_t fb_cap = 0;
     DevLight* d_lights = nullptr;   // emission sampler tables (PathTracerTest)
+    VtRec* d_vts = nullptr;          // textures: corner texture coordinates per slot, texture records, texel pool
+    DevTexture* d_textures = nullptr;
+    float* d_texels = nullptr;
     float* d_light_area = nullptr;
     int* d_light_slot = nullptr;
     int block = 256;
@@ -180,6 +183,12 @@ static void free_scene(MirtContext* ctx) {
     ctx->d_rnodes = nullptr;
     ctx->d_slot_node = nullptr;
     ctx->fast_tree = false;
+    hipFree(ctx->d_vts);
+    hipFree(ctx->d_textures);
+    hipFree(ctx->d_texels);
+    ctx->d_vts = nullptr;
+    ctx->d_textures = nullptr;
+    ctx->d_texels = nullptr;
     hipFree(ctx->d_lights);
     hipFree(ctx->d_light_area);
     hipFree(ctx->d_light_slot);
@@ -545,11 +554,30 @@ static void append_pairs(const TreeView& s, int slot_base, std::vector<PairRec>&
 
 int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     if (!ctx) return MIRT_E_INVALID;
-    // struct_size versions the descriptor: the form without per-object trees is still accepted
-    const size_t size_v1 = offsetof(MirtSceneDesc, n_obj_trees);
-    if (!s || (s->struct_size != sizeof(MirtSceneDesc) && s->struct_size != size_v1))
+    // struct_size versions the descriptor: the forms without per-object trees / without textures are still accepted
+    const size_t size_v1 = offsetof(MirtSceneDesc, n_obj_trees), size_v2 = offsetof(MirtSceneDesc, tri_vt);
+    if (!s || (s->struct_size != sizeof(MirtSceneDesc) && s->struct_size != size_v1 && s->struct_size != size_v2))
         return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: bad descriptor / struct_size");
-    const int n_obj_trees = s->struct_size == sizeof(MirtSceneDesc) ? s->n_obj_trees : 0;
+    const int n_obj_trees = s->struct_size >= size_v2 ? s->n_obj_trees : 0;
+    const bool tex_fields = s->struct_size == sizeof(MirtSceneDesc);
+    const int n_textures = tex_fields ? s->n_textures : 0;
+    const float* tri_vt = tex_fields ? s->tri_vt : nullptr;
+    const MirtObjectTex* object_tex = tex_fields && n_textures > 0 ? s->object_tex : nullptr;
+    if (n_textures < 0 || (n_textures > 0 && !s->textures))
+        return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: n_textures without textures");
+    size_t texel_total = 0;
+    for (int k = 0; k < n_textures; k++) {
+        const MirtTexture& X = s->textures[k];
+        if (X.width <= 0 || X.height <= 0 || (X.channels != 1 && X.channels != 3) || !X.texels ||
+            (long long)X.width * X.height > (1ll << 28))
+            return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: bad texture (size, channels or NULL texels)");
+        texel_total += (size_t)X.width * X.height * X.channels;
+    }
+    if (object_tex)
+        for (int o = 0; o < s->n_objects; o++)
+            for (int k : {object_tex[o].diffuse, object_tex[o].glossy_color, object_tex[o].glossy_coeff})
+                if (k < -1 || k >= n_textures)
+                    return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: object_tex index out of range");
     const MirtObjTree* obj_trees = n_obj_trees > 0 ? s->obj_trees : nullptr;
     if (s->n_nodes <= 0 || s->n_tris <= 0 || s->n_objects <= 0 || !s->node_min || !s->node_max ||
         !s->node_right || !s->node_leaf_begin || !s->node_leaf_end || !s->slot_tid || !s->tri_pos ||
@@ -718,12 +746,24 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     };
     const std::vector<int> main_src = seam_order(main_tree);  // device slot -> position in the reference's slot order
     for (int k = 0; k < T; k++) fill_slot((size_t)k, s->slot_tid[main_src[k]]);
+    std::vector<VtRec> vts(tri_vt ? TT : 0);
+    auto fill_vt = [&](size_t k, int g) {
+        const float* p = tri_vt + 9 * (size_t)g;
+        vts[k].t0 = make_float4(p[0], p[1], p[2], 0.f);
+        vts[k].t1 = make_float4(p[3], p[4], p[5], 0.f);
+        vts[k].t2 = make_float4(p[6], p[7], p[8], 0.f);
+    };
+    if (tri_vt)
+        for (int k = 0; k < T; k++) fill_vt((size_t)k, s->slot_tid[main_src[k]]);
     {
         size_t slot = (size_t)T;
         for (int k = 0; k < n_obj_trees; k++) {
             const MirtObject& ob = s->objects[obj_trees[k].object];
             const std::vector<int> src = seam_order(obj_view[k]);
-            for (int q = 0; q < ob.tri_count; q++) fill_slot(slot++, ob.tri_begin + obj_trees[k].slot_tid[src[q]]);
+            for (int q = 0; q < ob.tri_count; q++) {
+                if (tri_vt) fill_vt(slot, ob.tri_begin + obj_trees[k].slot_tid[src[q]]);
+                fill_slot(slot++, ob.tri_begin + obj_trees[k].slot_tid[src[q]]);
+            }
         }
     }
     std::vector<DevObject> objs(s->n_objects);
@@ -747,6 +787,10 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         }
         d.g = m.g;
         d.emit_pdf_a = 0.f;
+        d.tex_diffuse = object_tex ? object_tex[o].diffuse : -1;
+        d.tex_gcolor = object_tex ? object_tex[o].glossy_color : -1;
+        d.tex_gcoeff = object_tex ? object_tex[o].glossy_coeff : -1;
+        d.tex_pad = 0;
     }
     // Emission sampler (Scene::preprocessEmissionSampler, Scene.cpp:193-204 -> SurfaceSampler::preprocess,
     // Scene.cpp:19-33 -> SceneObject::preprocessEmissionSampler, SceneObject.cpp:11-21): per emissive
@@ -827,6 +871,28 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         HIPCHK(ctx, hipMemcpy(ctx->d_light_area, light_area.data(), sizeof(float) * light_area.size(), hipMemcpyHostToDevice));
         HIPCHK(ctx, hipMemcpy(ctx->d_light_slot, light_slot.data(), sizeof(int) * light_slot.size(), hipMemcpyHostToDevice));
     }
+    if (!vts.empty()) {
+        HIPCHK(ctx, hipMalloc(&ctx->d_vts, sizeof(VtRec) * vts.size()));
+        HIPCHK(ctx, hipMemcpy(ctx->d_vts, vts.data(), sizeof(VtRec) * vts.size(), hipMemcpyHostToDevice));
+    }
+    if (n_textures > 0) {
+        HIPCHK(ctx, hipMalloc(&ctx->d_texels, sizeof(float) * texel_total));
+        HIPCHK(ctx, hipMalloc(&ctx->d_textures, sizeof(DevTexture) * (size_t)n_textures));
+        std::vector<DevTexture> dt(n_textures);
+        size_t off = 0;
+        for (int k = 0; k < n_textures; k++) {
+            const MirtTexture& X = s->textures[k];
+            const size_t cnt = (size_t)X.width * X.height * X.channels;
+            HIPCHK(ctx, hipMemcpy(ctx->d_texels + off, X.texels, sizeof(float) * cnt, hipMemcpyHostToDevice));
+            dt[k].texels = ctx->d_texels + off;
+            dt[k].width = X.width, dt[k].height = X.height, dt[k].channels = X.channels, dt[k].pad = 0;
+            for (int q = 0; q < 12; q++) dt[k].coord[q] = X.coord_transform[q], dt[k].color[q] = X.color_transform[q];
+            off += cnt;
+        }
+        HIPCHK(ctx, hipMemcpy(ctx->d_textures, dt.data(), sizeof(DevTexture) * dt.size(), hipMemcpyHostToDevice));
+    }
+    ctx->sc.vts = ctx->d_vts;
+    ctx->sc.textures = ctx->d_textures;
     ctx->sc.lights = ctx->d_lights;
     ctx->sc.light_area = ctx->d_light_area;
     ctx->sc.light_slot = ctx->d_light_slot;

@@ -53,6 +53,18 @@ struct VnRec {
     float4 n0, n1, n2;  // .w: n0 bits(object id), n1 bits(global tid), n2 bits(object has vertex normals)
 };
 
+// corner texture coordinates of one slot (SimpleShape::vertexTexCoordList through the face's indices)
+struct VtRec {
+    float4 t0, t1, t2;  // xyz used
+};
+// one texture (Texture.h:14-42): texels in HBM, the first three rows of each matrix
+struct DevTexture {
+    const float* texels;
+    int width, height, channels, pad;
+    float coord[12];  // coordTransform rows 0..2, row-major
+    float color[12];  // colorTransform rows 0..2
+};
+
 struct DevObject {
     int type, has_vn, volumetric, pad;
     float color[3];
@@ -65,6 +77,7 @@ struct DevObject {
     float color2[3];   // MIRT_OBJ_PHONG: glossy colour (color = diffuse)
     float emit_pdf_a;  // emissive objects: weight / totalArea of the emission sampler (SceneObject.cpp:11-21,
                        // Scene.cpp:19-33), the area density PathTracerTest.cpp:38 uses for MIS
+    int tex_diffuse, tex_gcolor, tex_gcoeff, tex_pad;  // MirtObjectTex: indices into DevScene.textures, -1 none
 };
 // emission sampler tables (Scene::preprocessEmissionSampler, Scene.cpp:193-204): one record per
 // emissive object in scene order; its triangles' running areas live in DevScene.light_area / the
@@ -105,6 +118,8 @@ struct DevScene {
     const int* light_slot;     // slot of each light triangle
     int n_lights;
     float light_total_weight;  // SurfaceSampler::totalWeight
+    const VtRec* vts;          // per slot, or nullptr when the scene has no texture coordinates
+    const DevTexture* textures;
     int fast_ok;          // node bounds finite, < 2^60, extent per axis 0 or >= 2^-36: the slab classifier may be used
 };
 
@@ -331,6 +346,68 @@ __device__ __forceinline__ f3 world_normal(const TriRec& T, const VnRec& V, bool
        n2 = mk3(V.n2.x, V.n2.y, V.n2.z);
     f3 nn = ((1.f - u1 - u2) * n0 + u1 * n1) + u2 * n2;
     return normalize3(nn);
+}
+
+// ---- textures (Texture.cpp:43-94, SimpleShape.cpp:274-298) --------------------------------------
+// SimpleShape::getTexCoord: the barycentric weights of world_normal applied to the corner texture
+// coordinates; (0,0,0) for a scene without any
+__device__ __forceinline__ f3 tex_coord(const DevScene& sc, const TriRec& T, int slot, f3 pos) {
+    if (!sc.vts) return mk3(0, 0, 0);
+    const VtRec W = sc.vts[slot];
+    f3 v0 = mk3(T.a.x, T.a.y, T.a.z), v1 = mk3(T.b.x, T.b.y, T.b.z), v2 = mk3(T.c.x, T.c.y, T.c.z);
+    f3 b1 = v1 - v0, b2 = v2 - v0;
+    f3 v = pos - v0;
+    float d12 = dot3(b1, b2);
+    float l1 = len3(b1), l2 = len3(b2);
+    float vb1 = dot3(v, b1), vb2 = dot3(v, b2);
+    float u2 = (vb1 * d12 - vb2 * l1 * l1) / (d12 * d12 - l1 * l1 * l2 * l2);
+    float u1 = (vb1 - u2 * d12) / (l1 * l1);
+    return ((1.f - u1 - u2) * mk3(W.t0.x, W.t0.y, W.t0.z) + u1 * mk3(W.t1.x, W.t1.y, W.t1.z)) +
+           u2 * mk3(W.t2.x, W.t2.y, W.t2.z);
+}
+// rows 0..2 of M * (v, 1), accumulated left to right like nvMatrix.h's operator*
+__device__ __forceinline__ f3 apply_rows(const float* m, f3 v) {
+    return mk3(((v.x * m[0] + v.y * m[1]) + v.z * m[2]) + m[3], ((v.x * m[4] + v.y * m[5]) + v.z * m[6]) + m[7],
+               ((v.x * m[8] + v.y * m[9]) + v.z * m[10]) + m[11]);
+}
+// Texture::getColor: bilinear, wrapping, texel centres at +0.5; the gray branch reads its fourth texel
+// at (top, LEFT) as the reference does (Texture.cpp:86)
+__device__ __forceinline__ f3 tex_color(const DevTexture& X, f3 coord) {
+    const f3 tc = apply_rows(X.coord, coord);
+    float u = tc.x * (float)X.width - 0.5f;
+    float v = tc.y * (float)X.height - 0.5f;
+    int left = (int)floorf(u), bottom = (int)floorf(v);
+    int right = left + 1, top = bottom + 1;
+    u -= (float)left;
+    v -= (float)bottom;
+    left %= X.width;
+    right %= X.width;
+    top %= X.height;
+    bottom %= X.height;
+    if (left < 0) left += X.width;
+    if (right < 0) right += X.width;
+    if (top < 0) top += X.height;
+    if (bottom < 0) bottom += X.height;
+    const float wu = 1.f - u, wv = 1.f - v;
+    f3 color;
+    if (X.channels == 3) {
+        auto at = [&](int y, int x) {
+            const float* p = X.texels + 3 * ((size_t)y * X.width + x);
+            return mk3(p[0], p[1], p[2]);
+        };
+        color = mk3(0, 0, 0) + (at(bottom, left) * wu) * wv;
+        color = color + (at(bottom, right) * u) * wv;
+        color = color + (at(top, left) * wu) * v;
+        color = color + (at(top, right) * u) * v;
+    } else {
+        auto at = [&](int y, int x) { return X.texels[(size_t)y * X.width + x]; };
+        float c = 0.f + (at(bottom, left) * wu) * wv;
+        c = c + (at(bottom, right) * u) * wv;
+        c = c + (at(top, left) * wu) * v;
+        c = c + (at(top, left) * u) * v;
+        color = mk3(c, c, c);
+    }
+    return apply_rows(X.color, color);
 }
 
 // NoSelfIntersectionCondition.cpp:12-27; ids are object ids, -1 = NULL

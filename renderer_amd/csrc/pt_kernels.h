@@ -330,13 +330,28 @@ __device__ __forceinline__ void fresnel_split(f3 nn, f3 d, float cur_n, float ne
     nd = normalize3(nd);
 }
 
+// What an object's materials read at a point: the constant of the object, or its texture at
+// getTexCoord(triangle, at) (DiffuseMaterial.cpp:23,83,99; GlossyMaterial.cpp:11-12,66,74,78)
+__device__ __forceinline__ f3 diffuse_color(const DevScene& sc, const DevObject& ob, const TriRec& T, int slot, f3 at) {
+    if (ob.tex_diffuse >= 0) return tex_color(sc.textures[ob.tex_diffuse], tex_coord(sc, T, slot, at));
+    return mk3(ob.color[0], ob.color[1], ob.color[2]);
+}
+__device__ __forceinline__ f3 glossy_color(const DevScene& sc, const DevObject& ob, const TriRec& T, int slot, f3 at) {
+    if (ob.tex_gcolor >= 0) return tex_color(sc.textures[ob.tex_gcolor], tex_coord(sc, T, slot, at));
+    return ob.type == MIRT_OBJ_PHONG ? mk3(ob.color2[0], ob.color2[1], ob.color2[2]) : mk3(ob.color[0], ob.color[1], ob.color[2]);
+}
+__device__ __forceinline__ float glossy_coeff(const DevScene& sc, const DevObject& ob, const TriRec& T, int slot, f3 at) {
+    if (ob.tex_gcoeff >= 0) return tex_color(sc.textures[ob.tex_gcoeff], tex_coord(sc, T, slot, at)).x;
+    return ob.coeff;
+}
+
 // Material scatter of the object that was HIT (DiffuseMaterial.cpp:4-76, GlossyMaterial.cpp:4-56,
 // RefractiveMaterial.cpp:4-104, SceneEmissiveObject.cpp:4-19). `inside` = the incoming ray's inside
 // object. VOL: the scene holds volumetric objects, so leaving a refractive object asks
 // findInsideObject for the medium outside (RefractiveMaterial.cpp:52-53).
 template <bool VOL>
-__device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const DevObject& ob, int hobj, f3 nn, f3 pos,
-                                                   f3 d, int inside, uint32_t key, uint32_t& ctr) {
+__device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const DevObject& ob, int hobj, const TriRec& T,
+                                                   int slot, f3 nn, f3 pos, f3 d, int inside, uint32_t key, uint32_t& ctr) {
     Scatter r;
     r.pos = pos;
     r.nd = mk3(0, 0, 0);
@@ -350,16 +365,20 @@ __device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const Dev
     r.random = true;
     r.nn = nn;
     f3 col = mk3(ob.color[0], ob.color[1], ob.color[2]);
+    float coeff = ob.coeff;
     int type = ob.type;
     if (type == MIRT_OBJ_PHONG) {
         // SceneObject.cpp:366-373 with ScenePhongObject.h:16-19: one of {glossy, diffuse}, equal chance, one
         // draw of the path's stream; the chance is not divided out
-        if (rng_float(key, ctr) < 0.5f) {
-            type = MIRT_OBJ_GLOSSY;
-            col = mk3(ob.color2[0], ob.color2[1], ob.color2[2]);
-        } else {
-            type = MIRT_OBJ_DIFFUSE;
-        }
+        type = rng_float(key, ctr) < 0.5f ? MIRT_OBJ_GLOSSY : MIRT_OBJ_DIFFUSE;
+    }
+    if (type == MIRT_OBJ_DIFFUSE) {
+        col = diffuse_color(sc, ob, T, slot, pos);  // DiffuseMaterial.cpp:23: the texture at the hit point
+    } else if (type == MIRT_OBJ_GLOSSY) {
+        // GlossyMaterial.cpp:11-12 read the textures at getTexCoord(tid, outRay.origin) before outRay.origin is
+        // set (:17): a default-constructed vec3f, (0,0,0)
+        col = glossy_color(sc, ob, T, slot, mk3(0, 0, 0));
+        coeff = glossy_coeff(sc, ob, T, slot, mk3(0, 0, 0));
     }
     if (type == MIRT_OBJ_EMISSIVE) {
         // SceneEmissiveObject.cpp:4-19: the path ends; radiance only from the front side
@@ -387,17 +406,17 @@ __device__ __forceinline__ Scatter surface_scatter(const DevScene& sc, const Dev
         f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
         Frame olf = frame_from_normal(refl);
         float dx = rng_float(key, ctr), dy = rng_float(key, ctr);
-        f3 dir = to_world(olf, hemi_cos(ob.coeff, dx, dy));
+        f3 dir = to_world(olf, hemi_cos(coeff, dx, dy));
         f3 c = mk3(0, 0, 0);
         if (dot3(nn, d) <= 0.f && dot3(nn, dir) >= 0.f) {
             float rd = dot3(refl, dir);
-            if (rd > 0.f) c = col * powf(rd, ob.coeff);
+            if (rd > 0.f) c = col * powf(rd, coeff);
         }
         if (len3(c) != 0.f) {
             float p = max3f(col);
             if (rng_float(key, ctr) < p) {
                 r.color = c;
-                r.dirProb = cos_pdf(refl, dir, ob.coeff) * p;
+                r.dirProb = cos_pdf(refl, dir, coeff) * p;
                 r.nd = dir;
             }
         }
@@ -446,8 +465,9 @@ __device__ __forceinline__ uint32_t connection_key(uint32_t key) { return lowbia
 // vertex's contact object; `d`: direction of the ray that arrived at the vertex (lastRay.direction).
 // Six draws of the connection stream at 6 * vertexIndex: object, triangle, two for the point, two
 // for the emitted direction that the connection overwrites. Returns false when nothing can arrive.
-__device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObject& hob, f3 nn, f3 pos, f3 d,
-                                              uint32_t key, uint32_t vertex, f3& out_dir, float& out_dist, f3& contrib) {
+__device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObject& hob, const TriRec& T, int slot, f3 nn,
+                                              f3 pos, f3 d, uint32_t key, uint32_t vertex, f3& out_dir, float& out_dist,
+                                              f3& contrib) {
     if (sc.n_lights <= 0) return false;
     const uint32_t ck = connection_key(key);
     uint32_t cc = 6u * vertex;
@@ -479,7 +499,8 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
     ldir = normalize3(ldir);
     const f3 odir = neg(ldir);
     // lastRay.getBSDF(outRay): DiffuseMaterial.cpp:94-101, GlossyMaterial.cpp:69-79 (times max colour)
-    const f3 col = mk3(hob.color[0], hob.color[1], hob.color[2]);
+    // (the materials' textures at the vertex itself: DiffuseMaterial.cpp:83,99, GlossyMaterial.cpp:66,74,78)
+    const f3 col = diffuse_color(sc, hob, T, slot, pos);
     f3 bsdf = mk3(0, 0, 0);
     float pdf = 0.f;
     const bool sides = dot3(nn, d) <= 0.f && dot3(nn, odir) >= 0.f;
@@ -487,13 +508,14 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
         if (sides) bsdf = div3(col, 3.14159265358979f);
         pdf = max3f(col) * cos_pdf(nn, odir, 1.f);  // DiffuseMaterial.cpp:78-86
     } else if (hob.type == MIRT_OBJ_GLOSSY || hob.type == MIRT_OBJ_PHONG) {
-        const f3 gcol = hob.type == MIRT_OBJ_PHONG ? mk3(hob.color2[0], hob.color2[1], hob.color2[2]) : col;
+        const f3 gcol = glossy_color(sc, hob, T, slot, pos);
+        const float gcoeff = glossy_coeff(sc, hob, T, slot, pos);
         const f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
         if (sides) {
             const float rd = dot3(refl, odir);
-            if (rd > 0.f) bsdf = (gcol * powf(rd, hob.coeff)) * max3f(gcol);
+            if (rd > 0.f) bsdf = (gcol * powf(rd, gcoeff)) * max3f(gcol);
         }
-        pdf = cos_pdf(refl, odir, hob.coeff);  // GlossyMaterial.cpp:58-67
+        pdf = cos_pdf(refl, odir, gcoeff);  // GlossyMaterial.cpp:58-67
         if (hob.type == MIRT_OBJ_PHONG) {  // SceneObject.cpp:227-248, 341-352: BSDFs add, densities average
             bsdf = (mk3(0, 0, 0) + bsdf) + (sides ? div3(col, 3.14159265358979f) : mk3(0, 0, 0));
             pdf = (pdf + max3f(col) * cos_pdf(nn, odir, 1.f)) / 2.f;
@@ -644,12 +666,12 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                         sr.inside = through ? outside : sobj;
                         sr.originProb = vpm_p_surface(vo, t);
                     } else {  // a surface inside the medium: that object's scatter, from the hit point
-                        sr = surface_scatter<VOL>(sc, ob, hobj, nn, pos, d, sobj, key, ctr);
+                        sr = surface_scatter<VOL>(sc, ob, hobj, T, slot, nn, pos, d, sobj, key, ctr);
                         sr.originProb = sr.originProb * vpm_p_surface(vo, t);
                     }
                 }
             } else {
-                sr = surface_scatter<VOL>(sc, ob, hobj, nn, pos, d, inside, key, ctr);
+                sr = surface_scatter<VOL>(sc, ob, hobj, T, slot, nn, pos, d, inside, key, ctr);
             }
 
             if (NEE) {
@@ -676,7 +698,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                         if (sr.random) {  // PathTracerTest.cpp:59-63
                             f3 cdir, contrib;
                             float cdist;
-                            if (connect_light(sc, ob, nn, sr.pos, d, key, depth + 1, cdir, cdist, contrib)) {
+                            if (connect_light(sc, ob, T, slot, nn, sr.pos, d, key, depth + 1, cdir, cdist, contrib)) {
                                 shadow = true;
                                 sh_o = sr.pos;
                                 sh_d = cdir;

@@ -100,27 +100,41 @@ SceneObject* ConfigManager::generateSceneObject(XmlNode* nodeObj, XmlNode* nodeM
     // a <GroupObject> member takes its mesh AND transform from the split shape (ConfigManager.cpp:34-35:
     // the assignment comes after setTransform, so the member's own <transform> is overwritten)
     if (shape) *static_cast<SimpleShape*>(obj.get()) = *shape;
-    if (nodeMat->first_node("BumpTexture") || nodeMat->first_node("Texture") ||
-        nodeMat->first_node("ColorTexture") || nodeMat->first_node("CoeffTexture"))
-        throw std::runtime_error("ConfigManager: image / bump textures are outside this build (constant colours only)");
+    // ConfigManager.cpp:158-162: the bump texture perturbs the shading normal (SceneObject.cpp:250-283), which the
+    // hit predicate reads; not in this build
+    if (nodeMat->first_node("BumpTexture"))
+        throw std::runtime_error("ConfigManager: bump textures are outside this build");
+    // image textures (DiffuseMaterial.cpp:104-110, GlossyMaterial.cpp:88-98): the <color> / <coeff> constant
+    // stays in the material record, a texture node replaces it at shading time
+    auto loadTex = [&](XmlNode* parent, const char* tag) -> std::shared_ptr<Texture> {
+        XmlNode* n = parent->first_node(tag);
+        if (!n) return nullptr;
+        std::shared_ptr<Texture> t(new Texture);
+        t->loadTextureFromXML(this, n);
+        return t;
+    };
     if (type == "Diffuse") {
         m.type = MIRT_OBJ_DIFFUSE;
         if (nodeMat->first_node("color")) setColor(m.color, readVec(nodeMat->first_node("color")->value()));
+        obj->diffuseTex = loadTex(nodeMat, "Texture");
     } else if (type == "Glossy") {
         m.type = MIRT_OBJ_GLOSSY;
         if (nodeMat->first_node("color")) setColor(m.color, readVec(nodeMat->first_node("color")->value()));
         if (nodeMat->first_node("coeff")) m.coeff = (float)atof(nodeMat->first_node("coeff")->value());
+        obj->glossyColorTex = loadTex(nodeMat, "ColorTexture");
+        obj->glossyCoeffTex = loadTex(nodeMat, "CoeffTexture");
     } else if (type == "Phong") {  // ConfigManager.cpp:48-58, ScenePhongObject.h:7-23
         m.type = MIRT_OBJ_PHONG;
         XmlNode* g = nodeMat->first_node("GlossyComponent");
         XmlNode* df = nodeMat->first_node("DiffuseComponent");
         if (!g || !df) throw std::runtime_error("ConfigManager: Phong material needs <GlossyComponent> and <DiffuseComponent>");
-        if (g->first_node("ColorTexture") || g->first_node("CoeffTexture") || df->first_node("Texture"))
-            throw std::runtime_error("ConfigManager: image / bump textures are outside this build (constant colours only)");
         for (int c = 0; c < 3; c++) m.color2[c] = 1.f;  // GlossyMaterial / DiffuseMaterial default to white
         if (g->first_node("color")) setColor(m.color2, readVec(g->first_node("color")->value()));
         if (g->first_node("coeff")) m.coeff = (float)atof(g->first_node("coeff")->value());
         if (df->first_node("color")) setColor(m.color, readVec(df->first_node("color")->value()));
+        obj->glossyColorTex = loadTex(g, "ColorTexture");
+        obj->glossyCoeffTex = loadTex(g, "CoeffTexture");
+        obj->diffuseTex = loadTex(df, "Texture");
     } else if (type == "Emissive") {
         m.type = MIRT_OBJ_EMISSIVE;
         if (!nodeMat->first_node("color")) throw std::runtime_error("ConfigManager: Emissive material needs <color>");

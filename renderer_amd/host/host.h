@@ -73,12 +73,43 @@ public:
     bool hasVertexNormals() const;
 };
 
+class ConfigManager;
+
+// Texture.h:14-42 — an image (.pfm only, as in the reference: Texture.cpp:5-41) with a coordinate and a
+// colour transform. The lookups run on the device (mirt_dev.h tex_color); this class loads, holds and
+// describes the data, and keeps getColor for host-side checks.
+class Texture {
+public:
+    bool hasColor = true;
+    int width = 1, height = 1;
+    std::vector<float> values;   // gray texels
+    std::vector<vec3f> colors;   // rgb texels
+    matrix4 coordTransform, colorTransform;
+    void setCoordTransform(const matrix4& t) { coordTransform = t; }
+    void setColorTransform(const matrix4& t) { colorTransform = t; }
+    void loadFile(const std::string& fileName);  // throws std::runtime_error (the reference crashes on a missing file)
+    void setColor(const vec3f& color) {
+        hasColor = true;
+        colors.assign(1, color);
+        values.clear();
+        width = height = 1;
+    }
+    void toGrayScale();                                  // Texture.cpp:164-176
+    int size() const { return width * height; }
+    vec3f getColor(const vec3f& coord) const;            // Texture.cpp:43-94
+    void loadTextureFromXML(const ConfigManager* cm, XmlNode* nodeTex);  // Texture.cpp:149-162
+    MirtTexture describe() const;                        // pointers stay valid while the texture lives
+};
+
 // SceneObject.h:19-89 + the Scene*Object wrappers: one object = mesh + one material description
 class SceneObject : public SimpleShape {
 public:
     Scene* scene;
     int objectIndex;
     MirtObject material;  // type + parameters, what the device shades with
+    // image textures of the object's materials (null: the constant in `material`): DiffuseMaterial::tex,
+    // GlossyMaterial::colorTex / coeffTex (DiffuseMaterial.h:14, GlossyMaterial.h:14-15)
+    std::shared_ptr<Texture> diffuseTex, glossyColorTex, glossyCoeffTex;
     explicit SceneObject(Scene* scene);
     bool emissive() const { return material.type == MIRT_OBJ_EMISSIVE; }
     bool isVolumetric() const { return material.volumetric != 0; }
@@ -161,6 +192,13 @@ public:
     std::vector<int32_t> triObj, triLocal;
     std::vector<float> triVn;        // 9 per triangle
     std::vector<MirtObject> objectDescs;
+    // textures: corner texture coordinates (9 per triangle; empty when no object has any), the textures the
+    // objects' materials read and which object reads which
+    std::vector<float> triVt;
+    std::vector<std::shared_ptr<Texture>> textures;
+    std::vector<MirtTexture> textureDescs;
+    std::vector<MirtObjectTex> objectTex;
+    int addTexture(const std::shared_ptr<Texture>& t);  // index in `textures` (shared textures are stored once)
     // Scene::objKDTrees (Scene.h / Scene.cpp:287-320): built for the volumetric objects, the only
     // ones findInsideObject ever queries (Scene.cpp:369); empty trees elsewhere
     std::vector<KDTree> objKDTrees;
@@ -259,6 +297,7 @@ public:
     explicit ConfigManager(Renderer* r) : renderer(r) {}
     void load(const std::string& configFilePath);
     std::string getRootPath() const { return rootFolder; }
+    std::string getFullPath(const std::string& path) const { return resolve(path); }  // ConfigManager.h getFullPath
 
 private:
     Renderer* renderer;

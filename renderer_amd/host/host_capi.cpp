@@ -110,6 +110,57 @@ int mirth_scene_from_arrays(int32_t n_verts, const float* verts, int32_t n_tris,
     return 0;
 }
 
+int mirth_set_textures(MirthScene* s, const float* tri_vt, int32_t n_textures, const MirtTexture* textures,
+                       const MirtObjectTex* object_tex) {
+    if (!s || n_textures < 0 || (n_textures > 0 && (!textures || !object_tex))) {
+        g_err = "mirth_set_textures: NULL argument";
+        return -1;
+    }
+    Scene& sc = s->renderer.scene;
+    const size_t T = sc.tree.triangleList.size();
+    for (int k = 0; k < n_textures; k++)
+        if (textures[k].width <= 0 || textures[k].height <= 0 || !textures[k].texels ||
+            (textures[k].channels != 1 && textures[k].channels != 3)) {
+            g_err = "mirth_set_textures: bad texture";
+            return -1;
+        }
+    for (size_t o = 0; n_textures > 0 && o < sc.objectDescs.size(); o++)
+        for (int k : {object_tex[o].diffuse, object_tex[o].glossy_color, object_tex[o].glossy_coeff})
+            if (k < -1 || k >= n_textures) {
+                g_err = "mirth_set_textures: object_tex index out of range";
+                return -1;
+            }
+    sc.triVt.clear();
+    if (tri_vt) sc.triVt.assign(tri_vt, tri_vt + 9 * T);
+    sc.textures.clear();
+    sc.textureDescs.clear();
+    sc.objectTex.clear();
+    for (int k = 0; k < n_textures; k++) {
+        const MirtTexture& X = textures[k];
+        std::shared_ptr<Texture> t(new Texture);
+        t->width = X.width;
+        t->height = X.height;
+        t->hasColor = X.channels == 3;
+        const size_t n = (size_t)X.width * X.height;
+        t->colors.clear();
+        if (t->hasColor) {
+            t->colors.resize(n);
+            for (size_t i = 0; i < n; i++) t->colors[i] = vec3f(X.texels[3 * i], X.texels[3 * i + 1], X.texels[3 * i + 2]);
+        } else {
+            t->values.assign(X.texels, X.texels + n);
+        }
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) {
+                t->coordTransform(r, c) = X.coord_transform[4 * r + c];
+                t->colorTransform(r, c) = X.color_transform[4 * r + c];
+            }
+        sc.textures.push_back(t);
+        sc.textureDescs.push_back(t->describe());
+    }
+    if (n_textures > 0) sc.objectTex.assign(object_tex, object_tex + sc.objectDescs.size());
+    return 0;
+}
+
 void mirth_free(MirthScene* s) { delete s; }
 
 int mirth_counts(const MirthScene* s, int32_t out[5]) {

@@ -84,6 +84,10 @@ void Scene::clear() {
     triLocal.clear();
     triVn.clear();
     objectDescs.clear();
+    triVt.clear();
+    textures.clear();
+    textureDescs.clear();
+    objectTex.clear();
 }
 
 // Scene::buildKDTree (Scene.cpp:248-285): concatenate every object's world-space vertices and
@@ -97,6 +101,15 @@ void Scene::buildKDTree(bool upload) {
     triLocal.clear();
     triVn.clear();
     objectDescs.clear();
+    triVt.clear();
+    textures.clear();
+    textureDescs.clear();
+    objectTex.clear();
+    // corner texture coordinates are flattened only when some object has them for all its faces
+    // (SimpleShape::getTexCoord, SimpleShape.cpp:274-298, indexes faceVertexTexCoordIndexList by face)
+    bool any_vt = false;
+    for (const SceneObject* obj : objects)
+        any_vt |= !obj->vertexTexCoordList.empty() && obj->faceVertexTexCoordIndexList.size() == obj->faceVertexIndexList.size();
     unsigned vi_offset = 0, tri_offset = 0;
     for (unsigned oi = 0; oi < objects.size(); oi++) {
         SceneObject* obj = objects[oi];
@@ -104,7 +117,20 @@ void Scene::buildKDTree(bool upload) {
         for (unsigned i = 0; i < obj->getVertexNum(); i++)
             tree.vertexPositionList.push_back(obj->getWorldVertexPosition((int)i));
         const bool smooth = obj->hasVertexNormals();
+        const bool has_vt = !obj->vertexTexCoordList.empty() && obj->faceVertexTexCoordIndexList.size() == obj->faceVertexIndexList.size();
         for (unsigned i = 0; i < obj->getTriangleNum(); i++) {
+            if (any_vt)
+                for (int k = 0; k < 3; k++) {
+                    vec3f vt;  // (an object without texture coordinates reads (0,0,0), SimpleShape.cpp:276-277)
+                    if (has_vt) {
+                        const unsigned ti = obj->faceVertexTexCoordIndexList[i][k];
+                        if (ti >= obj->vertexTexCoordList.size()) throw std::runtime_error("Scene: texture coordinate index out of range in " + obj->name);
+                        vt = obj->vertexTexCoordList[ti];
+                    }
+                    triVt.push_back(vt.x);
+                    triVt.push_back(vt.y);
+                    triVt.push_back(vt.z);
+                }
             KDTree::Triangle tri;
             vec3ui v = obj->getVertexIndices((int)i);
             tri.vertexIndices = vec3ui{v.x + vi_offset, v.y + vi_offset, v.z + vi_offset};
@@ -133,10 +159,18 @@ void Scene::buildKDTree(bool upload) {
         m.tri_count = (int32_t)obj->getTriangleNum();
         obj->material = m;
         objectDescs.push_back(m);
+        MirtObjectTex ot;
+        ot.diffuse = addTexture(obj->diffuseTex);
+        ot.glossy_color = addTexture(obj->glossyColorTex);
+        ot.glossy_coeff = addTexture(obj->glossyCoeffTex);
+        ot.reserved = -1;
+        objectTex.push_back(ot);
         objTriangleOffsetMap.push_back(tri_offset);
         tri_offset += obj->getTriangleNum();
         vi_offset += obj->getVertexNum();
     }
+    textureDescs.clear();
+    for (const auto& t : textures) textureDescs.push_back(t->describe());
     tree.build();
     buildObjKDTrees();
     if (useGPU && upload) {
@@ -190,6 +224,14 @@ void Scene::buildObjKDTrees() {
     }
 }
 
+int Scene::addTexture(const std::shared_ptr<Texture>& t) {
+    if (!t) return -1;
+    for (size_t k = 0; k < textures.size(); k++)
+        if (textures[k] == t) return (int)k;
+    textures.push_back(t);
+    return (int)textures.size() - 1;
+}
+
 MirtSceneDesc Scene::describe() const {
     MirtSceneDesc d;
     memset(&d, 0, sizeof d);
@@ -210,6 +252,10 @@ MirtSceneDesc Scene::describe() const {
     d.objects = objectDescs.data();
     d.n_obj_trees = (int32_t)objTreeDescs.size();
     d.obj_trees = objTreeDescs.data();
+    d.tri_vt = triVt.empty() ? nullptr : triVt.data();
+    d.n_textures = (int32_t)textureDescs.size();
+    d.textures = textureDescs.empty() ? nullptr : textureDescs.data();
+    d.object_tex = textureDescs.empty() || objectTex.size() != objectDescs.size() ? nullptr : objectTex.data();
     return d;
 }
 

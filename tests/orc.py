@@ -32,6 +32,12 @@ def lib():
         L.orc_scene_create.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int32, C.c_void_p]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.orc_scene_set_textures.restype = None
+        L.orc_texture_color.argtypes = [C.c_void_p] * 3
+        L.orc_texture_color.restype = None
+        L.orc_tex_coord.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.orc_tex_coord.restype = None
         L.orc_tree_num_nodes.argtypes = [C.c_void_p]
         L.orc_tree_depth.argtypes = [C.c_void_p]
         L.orc_tree_flatten.argtypes = [C.c_void_p] * 7
@@ -91,6 +97,15 @@ class OracleScene:
                                         len(self.objects), _p(self.objects))
         self.n_nodes = lib().orc_tree_num_nodes(self.h)
         self.depth = lib().orc_tree_depth(self.h)
+        # textures (renderer_amd.make_texture dicts; OrcTexture has MirtTexture's layout)
+        if raw.get("textures"):
+            import renderer_amd as ra
+            self.tri_vt = None if raw.get("tri_vt") is None else np.ascontiguousarray(raw["tri_vt"], np.float32)
+            self.textures = raw["textures"]
+            self.object_tex = np.ascontiguousarray(raw["object_tex"], ra.OBJECT_TEX_DTYPE)
+            arr = ra.texture_structs(self.textures)
+            lib().orc_scene_set_textures(self.h, _p(self.tri_vt), len(self.textures), C.cast(arr, C.c_void_p),
+                                         _p(self.object_tex))
 
     def close(self):
         if self.h:
