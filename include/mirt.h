@@ -106,11 +106,16 @@ typedef struct MirtTexture {
  *   diffuse      DiffuseMaterial::tex       <Texture>       replaces color  (MIRT_OBJ_DIFFUSE, _PHONG)
  *   glossy_color GlossyMaterial::colorTex   <ColorTexture>  replaces color (MIRT_OBJ_GLOSSY) / color2 (_PHONG)
  *   glossy_coeff GlossyMaterial::coeffTex   <CoeffTexture>  replaces coeff (its .x)
+ *   bump         SceneObject::bumpTex       <BumpTexture>   perturbs the shading normal, which the hit predicate
+ *                of MIRT_MODE_NO_SELF reads too (SceneObject.cpp:250-283); a gray texture (ConfigManager.cpp:161);
+ *                set it only for objects that have texture coordinates and a texture of more than one texel
+ *                (SceneObject.cpp:253). Scenes with a bump texture run without the fast tree and cannot be
+ *                instrumented (mirt_intersect_count_dev / _audit_dev refuse them).
  * Texture coordinates come from tri_vt through SimpleShape::getTexCoord (SimpleShape.cpp:274-298).
  * GlossyMaterial::scatter reads its two textures at getTexCoord(tid, (0,0,0)) (GlossyMaterial.cpp:11-12
  * use outRay.origin before it is set at :17); the device does the same.                            */
 typedef struct MirtObjectTex {
-    int32_t diffuse, glossy_color, glossy_coeff, reserved;
+    int32_t diffuse, glossy_color, glossy_coeff, bump;
 } MirtObjectTex;
 
 /* Flattened scene: what KDTree::serializeForGPU (KDTree.cpp:346-383) + Scene::buildKDTree

@@ -119,6 +119,7 @@ struct OrcScene {
         int width = 1, height = 1, channels = 3;
         std::vector<float> texels;
         float coordT[16], colorT[16];
+        float coordInv[16];  // inverse(coordTransform), for Texture::getGrad
     };
     std::vector<V3> triVt;
     std::vector<Tex> textures;
@@ -251,13 +252,15 @@ V3 interpNormal(const V3 vps[3], const V3 vns[3], const V3& position) {  // Simp
     normalize(normal);
     return normal;
 }
-V3 worldNormal(const OrcScene& S, unsigned tid, const V3& position) {
+// SimpleShape::getWorldNormal (the unperturbed normal)
+V3 shapeNormal(const OrcScene& S, unsigned tid, const V3& position) {
     V3 vps[3];
     for (int i = 0; i < 3; i++) vps[i] = S.verts[S.tris[tid].v[i]];
     const OrcObject& obj = S.objects[S.triObj[tid]];
     if (!obj.has_vn || S.triVn.empty()) return faceNormalOf(vps);
     return interpNormal(vps, &S.triVn[3 * (size_t)tid], position);
 }
+V3 worldNormal(const OrcScene& S, unsigned tid, const V3& position);  // SceneObject::getWorldNormal, below
 
 // SimpleShape::getTexCoord (SimpleShape.cpp:274-298): barycentric weights from world positions, like
 // the normal interpolation; (0,0,0) for a shape without texture coordinates
@@ -321,6 +324,119 @@ V3 textureColor(const OrcScene::Tex& T, const V3& coord) {
     color += at(top, left) * (1 - u) * v;
     color += at(top, left) * u * v;
     return applyMat(T.colorT, V3(color, color, color), 1.f);
+}
+
+// inverse(matrix4) of nvMatrix.h:233-369: Gauss-Jordan with scaled partial pivoting in fp32; identity for a
+// singular matrix. Row-major in and out.
+void invertMat(const float m[16], float out[16]) {
+    for (int i = 0; i < 16; i++) out[i] = (i % 5 == 0) ? 1.f : 0.f;
+    float rows[4][8];
+    float* s[4] = {rows[0], rows[1], rows[2], rows[3]};
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            s[i][j] = m[4 * i + j];
+            s[i][j + 4] = i == j ? 1.f : 0.f;
+        }
+    float scp[4];
+    for (int i = 0; i < 4; i++) {
+        scp[i] = float(fabs(s[i][0]));
+        for (int j = 1; j < 4; j++)
+            if (float(fabs(s[i][j])) > scp[i]) scp[i] = float(fabs(s[i][j]));
+        if (scp[i] == 0.0) return;
+    }
+    for (int i = 0; i < 4; i++) {
+        int pivot_to = i;
+        float scp_max = float(fabs(s[i][i] / scp[i]));
+        for (int p = i + 1; p < 4; p++)
+            if (float(fabs(s[p][i] / scp[p])) > scp_max) {
+                scp_max = float(fabs(s[p][i] / scp[p]));
+                pivot_to = p;
+            }
+        if (pivot_to != i) {
+            std::swap(s[i], s[pivot_to]);
+            std::swap(scp[i], scp[pivot_to]);
+        }
+        for (int j = i + 1; j < 4; j++) {
+            float mji = s[j][i] / s[i][i];
+            s[j][i] = 0.0;
+            for (int jj = i + 1; jj < 8; jj++) s[j][jj] -= mji * s[i][jj];
+        }
+    }
+    if (s[3][3] == 0.0) return;
+    for (int i = 3; i > 0; i--)
+        for (int j = i - 1; j > -1; j--) {
+            float mij = s[j][i] / s[i][i];
+            for (int jj = j + 1; jj < 8; jj++) s[j][jj] -= mij * s[i][jj];
+        }
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) out[4 * i + j] = s[i][j + 4] / s[i][i];
+}
+// Texture::getGrad (Texture.cpp:96-147)
+V3 textureGrad(const OrcScene::Tex& T, const V3& coord) {
+    V3 tc = applyMat(T.coordT, coord, 1.f);
+    float u = tc.x * T.width - 0.5;
+    float v = tc.y * T.height - 0.5;
+    int left = (int)floor(u);
+    int right = left + 1;
+    int bottom = (int)floor(v);
+    int top = bottom + 1;
+    left %= T.width;
+    right %= T.width;
+    top %= T.height;
+    bottom %= T.height;
+    if (left < 0) left += T.width;
+    if (right < 0) right += T.width;
+    if (top < 0) top += T.height;
+    if (bottom < 0) bottom += T.height;
+    auto at = [&](int y, int x) { return T.texels[(size_t)T.channels * ((size_t)y * T.width + x)]; };  // .x of an rgb texel
+    V3 image_grad(0, 0, 0);
+    float lbColor = at(bottom, left);
+    image_grad.x = at(bottom, right) - lbColor;
+    image_grad.y = at(top, left) - lbColor;
+    float var_n = length(image_grad);
+    var_n = applyMat(T.colorT, V3(var_n, var_n, var_n), 0.f).x;
+    normalize(image_grad);
+    V3 uv_grad = applyMat(T.coordInv, image_grad, 0.f);
+    uv_grad.z = var_n;
+    return uv_grad;
+}
+// smallFuncs.h:11-24 applied to a direction (w = 0)
+V3 rotateDir(const V3& axis, float angle, const V3& v) {
+    float c = std::cos(angle), s = std::sin(angle);
+    float _c = 1 - c;
+    float x = axis.x, y = axis.y, z = axis.z;
+    float m00 = c + _c * x * x, m01 = _c * x * y - s * z, m02 = _c * x * z + s * y;
+    float m10 = _c * x * y + s * z, m11 = c + _c * y * y, m12 = _c * y * z - s * x;
+    float m20 = _c * x * z - s * y, m21 = _c * y * z + s * x, m22 = c + _c * z * z;
+    // nvMatrix.h:415-424 with src.w = 0
+    return V3(v.x * m00 + v.y * m01 + v.z * m02 + 0.f * 0.f, v.x * m10 + v.y * m11 + v.z * m12 + 0.f * 0.f,
+              v.x * m20 + v.y * m21 + v.z * m22 + 0.f * 0.f);
+}
+// SceneObject::getWorldNormal (SceneObject.cpp:250-283)
+V3 worldNormal(const OrcScene& S, unsigned tid, const V3& position) {
+    V3 original_normal = shapeNormal(S, tid, position);
+    if (S.objectTex.empty() || S.triVt.empty()) return original_normal;
+    const int bump = S.objectTex[S.triObj[tid]].bump;
+    if (bump < 0 || S.textures[bump].width * S.textures[bump].height <= 1) return original_normal;
+    V3 vps[3];
+    for (int i = 0; i < 3; i++) vps[i] = S.verts[S.tris[tid].v[i]];
+    const V3* vts = &S.triVt[3 * (size_t)tid];
+    V3 uv_grad = textureGrad(S.textures[bump], texCoord(S, tid, position));
+    V3 b1 = vps[1] - vps[0];
+    V3 b2 = vps[2] - vps[0];
+    V3 duv1 = vts[1] - vts[0];
+    V3 duv2 = vts[2] - vts[0];
+    float k2 = (uv_grad.x * duv1.y - uv_grad.y * duv1.x) / (duv1.y * duv2.x - duv1.x * duv2.y);
+    float k1 = (uv_grad.y - k2 * duv2.y) / duv1.y;
+    normalize(b1);
+    normalize(b2);
+    V3 dl = k1 * b1 + k2 * b2;
+    V3 dh = original_normal * uv_grad.z;
+    if (length(dh) * 1000 < length(dl)) return original_normal;
+    float angle = atan2(length(dh), length(dl));
+    V3 axis = cross(dl, dh);
+    normalize(axis);
+    return rotateDir(axis, angle, original_normal);
 }
 
 // NoSelfIntersectionCondition.cpp:12-27
@@ -875,18 +991,7 @@ struct Tracer {
     }
 
     // smallFuncs.h:11-24 applied to a direction (w = 0)
-    static V3 rotate(const V3& axis, float angle, const V3& v) {
-        float c = std::cos(angle), s = std::sin(angle);
-        float _c = 1 - c;
-        float x = axis.x, y = axis.y, z = axis.z;
-        float m00 = c + _c * x * x, m01 = _c * x * y - s * z, m02 = _c * x * z + s * y;
-        float m10 = _c * x * y + s * z, m11 = c + _c * y * y, m12 = _c * y * z - s * x;
-        float m20 = _c * x * z - s * y, m21 = _c * y * z + s * x, m22 = c + _c * z * z;
-        // nvMatrix.h:415-424 with src.w = 0
-        return V3(v.x * m00 + v.y * m01 + v.z * m02 + 0.f * 0.f,
-                  v.x * m10 + v.y * m11 + v.z * m12 + 0.f * 0.f,
-                  v.x * m20 + v.y * m21 + v.z * m22 + 0.f * 0.f);
-    }
+    static V3 rotate(const V3& axis, float angle, const V3& v) { return rotateDir(axis, angle, v); }
     static float clampf(float v, float lo, float hi) { return v < lo ? lo : v > hi ? hi : v; }
 
     // RefractiveMaterial.cpp:4-104
@@ -1620,6 +1725,7 @@ void orc_scene_set_textures(OrcScene* S, const float* tri_vt, int32_t n_textures
         T.texels.assign(textures[k].texels, textures[k].texels + (size_t)T.width * T.height * T.channels);
         memcpy(T.coordT, textures[k].coord_transform, sizeof T.coordT);
         memcpy(T.colorT, textures[k].color_transform, sizeof T.colorT);
+        invertMat(T.coordT, T.coordInv);
     }
     S->objectTex.clear();
     if (object_tex && n_textures > 0) S->objectTex.assign(object_tex, object_tex + S->objects.size());

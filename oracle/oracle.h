@@ -54,7 +54,7 @@ typedef struct OrcTexture {
 } OrcTexture;
 /* which textures an object's materials read (-1: the constant of OrcObject); same layout as MirtObjectTex */
 typedef struct OrcObjectTex {
-    int32_t diffuse, glossy_color, glossy_coeff, reserved;
+    int32_t diffuse, glossy_color, glossy_coeff, bump; /* bump: SceneObject::bumpTex, gray, objects with texture coordinates only */
 } OrcObjectTex;
 
 typedef struct OrcCamera {

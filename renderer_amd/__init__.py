@@ -59,7 +59,7 @@ class Texture(C.Structure):
 
 
 # MirtObjectTex: which texture (index, -1 none) each of an object's materials reads
-OBJECT_TEX_DTYPE = np.dtype([("diffuse", "<i4"), ("glossy_color", "<i4"), ("glossy_coeff", "<i4"), ("reserved", "<i4")])
+OBJECT_TEX_DTYPE = np.dtype([("diffuse", "<i4"), ("glossy_color", "<i4"), ("glossy_coeff", "<i4"), ("bump", "<i4")])
 
 
 def make_texture(texels, coord_transform=None, color_transform=None):

@@ -58,7 +58,7 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
         const VnRec V = sc.vns[s];
         const int hobj = __float_as_int(V.n0.w);
         const f3 pos = o + d * t;
-        const f3 nn = world_normal(T, V, __float_as_int(V.n2.w) != 0, pos);
+        const f3 nn = shading_normal<false>(sc, T, V, s, pos);
         return legal_noself(dot3(d, nn), hobj, contact, inside);
     }
     return true;
@@ -76,12 +76,14 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
 // misses it; proven hits and unproven boxes are both entered), the result is written as (t, SLOT) and
 // k_verify decides whether it is the reference's answer. Rays outside the classifier's error model are
 // not traversed at all (k_verify sends them to the exact kernel).
+// BUMP: the scene has bump textures (SceneObject.cpp:250-283): the predicate's normal is the perturbed one.
+// Only the NO_SELF instantiations differ; scenes without bump textures never run them.
 // ray_list != nullptr: the queue hands out positions of ray_list, which holds the ray indices (the
 // exact re-run of the rays k_verify rejected).
 #ifndef MIRT_WAVES_PER_EU
 #define MIRT_WAVES_PER_EU 5
 #endif
-template <int MODE, bool COUNT, bool SLOT_OUT, bool ANYHIT = false, bool FAST = false>
+template <int MODE, bool COUNT, bool SLOT_OUT, bool ANYHIT = false, bool FAST = false, bool BUMP = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_WAVES_PER_EU, MIRT_WAVES_PER_EU)))
 k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ D,
             const int* __restrict__ aux, uint32_t n_direct, const uint32_t* __restrict__ n_ptr,
@@ -326,7 +328,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 if (cand >= 0) {
                     const VnRec V = sc.vns[cand];
                     const f3 pos = o + d * cand_t;
-                    const f3 nn = world_normal(sc.tris[cand], V, __float_as_int(V.n2.w) != 0, pos);
+                    const f3 nn = shading_normal<BUMP>(sc, sc.tris[cand], V, cand, pos);
                     if (legal_noself(dot3(d, nn), __float_as_int(V.n0.w), unpack_contact(a), unpack_inside(a)))
                         accept(cand_t, cand);
                 }
@@ -486,7 +488,7 @@ k_rerun(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, c
                     if (!(t >= 0.f)) continue;
                     if (!(best_slot < 0 || t < best || (t == best && best_leaf < beg))) continue;
                     const VnRec V = sc.vns[s];
-                    const f3 nn = world_normal(T, V, __float_as_int(V.n2.w) != 0, o + d * t);
+                    const f3 nn = shading_normal<false>(sc, T, V, s, o + d * t);
                     if (!legal_noself(dot3(d, nn), __float_as_int(V.n0.w), contact, inside)) continue;
                     best = t;
                     best_slot = s;

@@ -15,6 +15,7 @@
 
 #include "intersect_kernels.h"
 #include "pt_kernels.h"
+#include "../host/vecmath.h"  // matrix4::inverse (the scheme of nvMatrix.h:233-369) for Texture::getGrad
 
 #pragma clang fp contract(off)
 
@@ -45,6 +46,8 @@ struct MirtContext {
     VtRec* d_vts = nullptr;          // textures: corner texture coordinates per slot, texture records, texel pool
     DevTexture* d_textures = nullptr;
     float* d_texels = nullptr;
+    DevBump* d_bumps = nullptr;
+    bool has_bump = false;
     float* d_light_area = nullptr;
     int* d_light_slot = nullptr;
     int block = 256;
@@ -186,6 +189,9 @@ static void free_scene(MirtContext* ctx) {
     hipFree(ctx->d_vts);
     hipFree(ctx->d_textures);
     hipFree(ctx->d_texels);
+    hipFree(ctx->d_bumps);
+    ctx->d_bumps = nullptr;
+    ctx->has_bump = false;
     ctx->d_vts = nullptr;
     ctx->d_textures = nullptr;
     ctx->d_texels = nullptr;
@@ -575,9 +581,28 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     }
     if (object_tex)
         for (int o = 0; o < s->n_objects; o++)
-            for (int k : {object_tex[o].diffuse, object_tex[o].glossy_color, object_tex[o].glossy_coeff})
+            for (int k : {object_tex[o].diffuse, object_tex[o].glossy_color, object_tex[o].glossy_coeff, object_tex[o].bump})
                 if (k < -1 || k >= n_textures)
                     return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: object_tex index out of range");
+    // bump textures (SceneObject.cpp:250-283): one DevBump per object that has one; needs texture coordinates
+    std::vector<DevBump> bumps;
+    std::vector<int> obj_bump(std::max(s->n_objects, 0), 0);  // 1 + index into bumps, 0 = none
+    if (object_tex)
+        for (int o = 0; o < s->n_objects; o++) {
+            const int k = object_tex[o].bump;
+            if (k < 0) continue;
+            if (!tri_vt) return fail(ctx, MIRT_E_INVALID, "mirt_upload_scene: a bump texture needs tri_vt");
+            const MirtTexture& X = s->textures[k];
+            mirt_host::matrix4 m;
+            for (int r = 0; r < 4; r++)
+                for (int c = 0; c < 4; c++) m(r, c) = X.coord_transform[4 * r + c];
+            const mirt_host::matrix4 inv = m.inverse();
+            DevBump B;
+            B.texture = k;
+            for (int q = 0; q < 12; q++) B.inv[q] = inv(q / 4, q % 4);
+            bumps.push_back(B);
+            obj_bump[o] = (int)bumps.size();
+        }
     const MirtObjTree* obj_trees = n_obj_trees > 0 ? s->obj_trees : nullptr;
     if (s->n_nodes <= 0 || s->n_tris <= 0 || s->n_objects <= 0 || !s->node_min || !s->node_max ||
         !s->node_right || !s->node_leaf_begin || !s->node_leaf_end || !s->slot_tid || !s->tri_pos ||
@@ -741,7 +766,8 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         vns[k].n0 = make_float4(vn ? vn[0] : fnrm.x, vn ? vn[1] : fnrm.y, vn ? vn[2] : fnrm.z, fo);
         vns[k].n1 = make_float4(vn ? vn[3] : 0.f, vn ? vn[4] : 0.f, vn ? vn[5] : 0.f, fg);
         float fh;
-        memcpy(&fh, &hv, 4);
+        const int flags = hv | (obj_bump[ob] << 8);  // shading_normal (mirt_dev.h)
+        memcpy(&fh, &flags, 4);
         vns[k].n2 = make_float4(vn ? vn[6] : 0.f, vn ? vn[7] : 0.f, vn ? vn[8] : 0.f, fh);
     };
     const std::vector<int> main_src = seam_order(main_tree);  // device slot -> position in the reference's slot order
@@ -891,6 +917,14 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         }
         HIPCHK(ctx, hipMemcpy(ctx->d_textures, dt.data(), sizeof(DevTexture) * dt.size(), hipMemcpyHostToDevice));
     }
+    if (!bumps.empty()) {
+        HIPCHK(ctx, hipMalloc(&ctx->d_bumps, sizeof(DevBump) * bumps.size()));
+        HIPCHK(ctx, hipMemcpy(ctx->d_bumps, bumps.data(), sizeof(DevBump) * bumps.size(), hipMemcpyHostToDevice));
+    }
+    ctx->has_bump = !bumps.empty();
+    ctx->sc.bumps = ctx->d_bumps;
+    ctx->sc.has_bump = ctx->has_bump ? 1 : 0;
+    if (ctx->has_bump) ctx->fast_tree = false;  // k_verify / k_rerun are built without the bump branch
     ctx->sc.vts = ctx->d_vts;
     ctx->sc.textures = ctx->d_textures;
     ctx->sc.lights = ctx->d_lights;
@@ -951,6 +985,14 @@ template <int MODE, bool COUNT, bool SLOT_OUT, bool FAST>
 static void launch_pair(MirtContext* ctx, hipStream_t st, dim3 grid, dim3 block, const float* O, const float* D,
                         const int* aux, uint32_t n, const uint32_t* n_ptr, uint32_t stride, float* t_out,
                         int* id_out, uint32_t* queue, const uint32_t* ray_list) {
+    if constexpr (MODE == MIRT_MODE_NO_SELF && !COUNT && !FAST) {
+        if (ctx->has_bump) {  // the predicate reads the bumped normal (SceneObject.cpp:250-283)
+            hipLaunchKernelGGL((k_intersect<MODE, false, SLOT_OUT, false, false, true>), grid, block, ctx->lds_main, st,
+                               ctx->sc, O, D, aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue,
+                               ctx->lds_levels, ctx->d_spill, (const float*)nullptr, (unsigned char*)nullptr, ray_list);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT, false, FAST>), grid, block, ctx->lds_main, st, ctx->sc, O, D,
                        aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue, ctx->lds_levels, ctx->d_spill,
                        (const float*)nullptr, (unsigned char*)nullptr, ray_list);
@@ -968,6 +1010,7 @@ static int launch_mode(MirtContext* ctx, hipStream_t st, dim3 grid, dim3 block, 
             launch_pair<MIRT_MODE_LAST_TID, COUNT, SLOT_OUT, FAST>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue, ray_list);
             break;
         case MIRT_MODE_NO_SELF:
+            if (COUNT && ctx->has_bump) return fail(ctx, MIRT_E_INVALID, "intersect: scenes with bump textures cannot be instrumented");
             launch_pair<MIRT_MODE_NO_SELF, COUNT, SLOT_OUT, FAST>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue, ray_list);
             break;
         default:
@@ -1053,7 +1096,14 @@ static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const f
     switch (mode) {
         case MIRT_MODE_UNCONDITIONAL: MIRT_VIS(MIRT_MODE_UNCONDITIONAL); break;
         case MIRT_MODE_LAST_TID: MIRT_VIS(MIRT_MODE_LAST_TID); break;
-        case MIRT_MODE_NO_SELF: MIRT_VIS(MIRT_MODE_NO_SELF); break;
+        case MIRT_MODE_NO_SELF:
+            if (ctx->has_bump)
+                hipLaunchKernelGGL((k_intersect<MIRT_MODE_NO_SELF, false, false, true, false, true>), grid, block, ctx->lds_main,
+                                   st, ctx->sc, O, D, aux, n, n_ptr, stride, (float*)nullptr, (int*)nullptr, ctx->d_counters,
+                                   queue, ctx->lds_levels, ctx->d_spill, limit, vis_out);
+            else
+                MIRT_VIS(MIRT_MODE_NO_SELF);
+            break;
         default: return fail(ctx, MIRT_E_INVALID, "visibility: unknown mode");
     }
 #undef MIRT_VIS

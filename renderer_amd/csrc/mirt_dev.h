@@ -120,6 +120,8 @@ struct DevScene {
     float light_total_weight;  // SurfaceSampler::totalWeight
     const VtRec* vts;          // per slot, or nullptr when the scene has no texture coordinates
     const DevTexture* textures;
+    const struct DevBump* bumps;  // bump textures of the objects that have one (VnRec.n2.w bits 8..)
+    int has_bump;
     int fast_ok;          // node bounds finite, < 2^60, extent per axis 0 or >= 2^-36: the slab classifier may be used
 };
 
@@ -408,6 +410,77 @@ __device__ __forceinline__ f3 tex_color(const DevTexture& X, f3 coord) {
         color = mk3(c, c, c);
     }
     return apply_rows(X.color, color);
+}
+
+// Texture::getGrad (Texture.cpp:96-147): forward differences of the texel under the coordinate (first
+// channel of an rgb texture), their length through the colour transform as .z, their direction through
+// the inverse coordinate transform as .xy. `inv`: rows 0..2 of inverse(coordTransform), from the host.
+struct DevBump {
+    int texture;     // index into DevScene.textures
+    float inv[12];
+};
+__device__ __forceinline__ f3 tex_grad(const DevTexture& X, const float* inv, f3 coord) {
+    const f3 tc = apply_rows(X.coord, coord);
+    const float u = tc.x * (float)X.width - 0.5f;
+    const float v = tc.y * (float)X.height - 0.5f;
+    int left = (int)floorf(u), bottom = (int)floorf(v);
+    int right = left + 1, top = bottom + 1;
+    left %= X.width;
+    right %= X.width;
+    top %= X.height;
+    bottom %= X.height;
+    if (left < 0) left += X.width;
+    if (right < 0) right += X.width;
+    if (top < 0) top += X.height;
+    if (bottom < 0) bottom += X.height;
+    const int ch = X.channels;
+    auto at = [&](int y, int x) { return X.texels[ch * ((size_t)y * X.width + x)]; };
+    const float lb = at(bottom, left);
+    f3 g = mk3(at(bottom, right) - lb, at(top, left) - lb, 0.f);
+    float var_n = len3(g);
+    var_n = ((var_n * X.color[0] + var_n * X.color[1]) + var_n * X.color[2]) + 0.f * X.color[3];
+    g = normalize3(g);
+    f3 r = mk3(((g.x * inv[0] + g.y * inv[1]) + g.z * inv[2]) + 0.f * inv[3],
+               ((g.x * inv[4] + g.y * inv[5]) + g.z * inv[6]) + 0.f * inv[7], var_n);
+    return r;
+}
+// smallFuncs.h:11-24 (rotMat) applied to a direction
+__device__ __forceinline__ f3 rot_about(f3 axis, float angle, f3 v) {
+    const float c = cosf(angle), s = sinf(angle), ic = 1.f - c;
+    const float x = axis.x, y = axis.y, z = axis.z;
+    return mk3(v.x * (c + ic * x * x) + v.y * (ic * x * y - s * z) + v.z * (ic * x * z + s * y),
+               v.x * (ic * x * y + s * z) + v.y * (c + ic * y * y) + v.z * (ic * y * z - s * x),
+               v.x * (ic * x * z - s * y) + v.y * (ic * y * z + s * x) + v.z * (c + ic * z * z));
+}
+// SceneObject::getWorldNormal's bump branch (SceneObject.cpp:258-282): the interpolated normal `n` tilted
+// towards the texture's gradient, expressed in the triangle's edge directions through the corner
+// texture coordinates. (The libm calls - atan2, sin, cos - are the device's: not bit-identical to glibc's.)
+__device__ __forceinline__ f3 bump_normal(const DevScene& sc, const TriRec& T, int slot, const DevBump& B, f3 n, f3 pos) {
+    const VtRec W = sc.vts[slot];
+    const f3 g = tex_grad(sc.textures[B.texture], B.inv, tex_coord(sc, T, slot, pos));
+    f3 b1 = mk3(T.b.x, T.b.y, T.b.z) - mk3(T.a.x, T.a.y, T.a.z), b2 = mk3(T.c.x, T.c.y, T.c.z) - mk3(T.a.x, T.a.y, T.a.z);
+    const f3 duv1 = mk3(W.t1.x, W.t1.y, W.t1.z) - mk3(W.t0.x, W.t0.y, W.t0.z);
+    const f3 duv2 = mk3(W.t2.x, W.t2.y, W.t2.z) - mk3(W.t0.x, W.t0.y, W.t0.z);
+    const float k2 = (g.x * duv1.y - g.y * duv1.x) / (duv1.y * duv2.x - duv1.x * duv2.y);
+    const float k1 = (g.y - k2 * duv2.y) / duv1.y;
+    b1 = normalize3(b1);
+    b2 = normalize3(b2);
+    const f3 dl = k1 * b1 + k2 * b2;
+    const f3 dh = n * g.z;
+    if (len3(dh) * 1000.f < len3(dl)) return n;
+    const float angle = atan2f(len3(dh), len3(dl));
+    const f3 axis = normalize3(cross3(dl, dh));
+    return rot_about(axis, angle, n);
+}
+// SceneObject::getWorldNormal (SceneObject.cpp:250-283). VnRec.n2.w: bit 0 = the object interpolates vertex
+// normals, bits 8.. = 1 + index into DevScene.bumps when the object has a bump texture AND texture
+// coordinates. BUMP false: the scene has no bump textures (the instantiations every other scene runs).
+template <bool BUMP>
+__device__ __forceinline__ f3 shading_normal(const DevScene& sc, const TriRec& T, const VnRec& V, int slot, f3 pos) {
+    const int flags = __float_as_int(V.n2.w);
+    f3 n = world_normal(T, V, (flags & 1) != 0, pos);
+    if (BUMP && (flags >> 8) != 0) n = bump_normal(sc, T, slot, sc.bumps[(flags >> 8) - 1], n, pos);
+    return n;
 }
 
 // NoSelfIntersectionCondition.cpp:12-27; ids are object ids, -1 = NULL

@@ -148,14 +148,8 @@ __device__ __forceinline__ float max3f(f3 c) { return fmaxf(c.x, fmaxf(c.y, c.z)
 __device__ __forceinline__ float clampf(float v, float lo, float hi) {
     return v < lo ? lo : (v > hi ? hi : v);
 }
-// smallFuncs.h:11-24 applied to a direction
-__device__ __forceinline__ f3 rotate_about(f3 axis, float angle, f3 v) {
-    float c = cosf(angle), s = sinf(angle), ic = 1.f - c;
-    float x = axis.x, y = axis.y, z = axis.z;
-    return mk3(v.x * (c + ic * x * x) + v.y * (ic * x * y - s * z) + v.z * (ic * x * z + s * y),
-               v.x * (ic * x * y + s * z) + v.y * (c + ic * y * y) + v.z * (ic * y * z - s * x),
-               v.x * (ic * x * z - s * y) + v.y * (ic * y * z + s * x) + v.z * (c + ic * z * z));
-}
+// smallFuncs.h:11-24 applied to a direction (mirt_dev.h rot_about)
+__device__ __forceinline__ f3 rotate_about(f3 axis, float angle, f3 v) { return rot_about(axis, angle, v); }
 // SceneObject.h:58 / SceneRefractiveObject.h:22: mirrors keep the default 1
 __device__ __forceinline__ float refr_coeff(const DevObject& o) {
     return (o.type == MIRT_OBJ_REFRACTIVE && o.ior >= 0.f) || o.type == MIRT_OBJ_VPM ? o.ior : 1.f;
@@ -237,12 +231,12 @@ __device__ inline int find_inside(const DevScene& sc, f3 o, f3 d, int current) {
         float dist = trace_object(sc, R, o, bd, slot);
         if (dist < 1e-6f) continue;
         VnRec V = sc.vns[slot];
-        f3 n = world_normal(sc.tris[slot], V, __float_as_int(V.n2.w) != 0, o + bd * dist);
+        f3 n = shading_normal<true>(sc, sc.tris[slot], V, slot, o + bd * dist);
         if (dot3(n, bd) < 1e-6f) continue;
         dist = trace_object(sc, R, o, d, slot);
         if (dist < 1e-6f) continue;
         V = sc.vns[slot];
-        n = world_normal(sc.tris[slot], V, __float_as_int(V.n2.w) != 0, o + d * dist);
+        n = shading_normal<true>(sc, sc.tris[slot], V, slot, o + d * dist);
         if (dot3(n, d) < 1e-6f) continue;
         return R.object;
     }
@@ -523,7 +517,7 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
     }
     if (lum_y(bsdf) < 1e-7f) return false;
     const VnRec LV = sc.vns[lslot];
-    const f3 nl = world_normal(LT, LV, __float_as_int(LV.n2.w) != 0, y);
+    const f3 nl = shading_normal<true>(sc, LT, LV, lslot, y);
     const float cos_at_light = fminf(fmaxf(0.f, fabsf(dot3(nl, ldir))), 1.f);
     if (cos_at_light < 1e-6f) return false;
     const float cos_to_light = fminf(fmaxf(0.f, fabsf(dot3(nn, odir))), 1.f);
@@ -587,7 +581,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
             const int hobj = __float_as_int(V.n0.w);
             const DevObject ob = sc.objects[hobj];
             const f3 pos = o + d * t;
-            const f3 nn = world_normal(T, V, ob.has_vn != 0, pos);
+            const f3 nn = shading_normal<true>(sc, T, V, slot, pos);
 
             // whose scatter() runs (MCRenderer.cpp:167-174): the inside object's if there is one; a
             // refractive inside object hands a hit on another object to that object
@@ -707,7 +701,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                                 sh_ids = MIRT_PACK_IDS(sr.contact, sr.inside);
                             }
                         }
-                        if (len3(sr.nd) >= 0.5f) {  // PathTracerTest.cpp:68-76
+                        if (!(len3(sr.nd) < 0.5f)) {  // PathTracerTest.cpp:68-76 (a NaN direction goes on, MCRenderer.cpp:181)
                             lpw = sr.random ? sr.dirProb : -1.f;
                             float ct = fabsf(dot3(sr.nn, sr.nd));
                             ct = ct > 1e-6f ? ct : 1e-6f;
@@ -747,7 +741,9 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                 L[pid] = rad.x;
                 L[L_stride + pid] = rad.y;
                 L[2 * L_stride + pid] = rad.z;
-            } else if (len3(nd) >= 0.5f) {
+            } else if (!(len3(nd) < 0.5f)) {
+                // (MCRenderer.cpp:181 ends the path when length < 0.5: a NaN direction, e.g. from a bump-mapped
+                // triangle whose first edge runs along u (SceneObject.cpp:272 divides by duv1.y), is traced and misses)
                 // Ray.cpp:71-78: cosine term of the new vertex against its contact normal
                 float ct = 1.f;
                 if (sr.cos_term) ct = fabsf(dot3(sr.nn, nd));

@@ -100,10 +100,6 @@ SceneObject* ConfigManager::generateSceneObject(XmlNode* nodeObj, XmlNode* nodeM
     // a <GroupObject> member takes its mesh AND transform from the split shape (ConfigManager.cpp:34-35:
     // the assignment comes after setTransform, so the member's own <transform> is overwritten)
     if (shape) *static_cast<SimpleShape*>(obj.get()) = *shape;
-    // ConfigManager.cpp:158-162: the bump texture perturbs the shading normal (SceneObject.cpp:250-283), which the
-    // hit predicate reads; not in this build
-    if (nodeMat->first_node("BumpTexture"))
-        throw std::runtime_error("ConfigManager: bump textures are outside this build");
     // image textures (DiffuseMaterial.cpp:104-110, GlossyMaterial.cpp:88-98): the <color> / <coeff> constant
     // stays in the material record, a texture node replaces it at shading time
     auto loadTex = [&](XmlNode* parent, const char* tag) -> std::shared_ptr<Texture> {
@@ -113,6 +109,12 @@ SceneObject* ConfigManager::generateSceneObject(XmlNode* nodeObj, XmlNode* nodeM
         t->loadTextureFromXML(this, n);
         return t;
     };
+    // ConfigManager.cpp:158-162: any material may carry a bump texture; it perturbs the object's shading normal
+    // (SceneObject.cpp:250-283) and is reduced to one channel
+    if (nodeMat->first_node("BumpTexture")) {
+        obj->bumpTex = loadTex(nodeMat, "BumpTexture");
+        obj->bumpTex->toGrayScale();
+    }
     if (type == "Diffuse") {
         m.type = MIRT_OBJ_DIFFUSE;
         if (nodeMat->first_node("color")) setColor(m.color, readVec(nodeMat->first_node("color")->value()));

@@ -110,6 +110,7 @@ public:
     // image textures of the object's materials (null: the constant in `material`): DiffuseMaterial::tex,
     // GlossyMaterial::colorTex / coeffTex (DiffuseMaterial.h:14, GlossyMaterial.h:14-15)
     std::shared_ptr<Texture> diffuseTex, glossyColorTex, glossyCoeffTex;
+    std::shared_ptr<Texture> bumpTex;  // SceneObject::bumpTex (SceneObject.h:34), gray (ConfigManager.cpp:161)
     explicit SceneObject(Scene* scene);
     bool emissive() const { return material.type == MIRT_OBJ_EMISSIVE; }
     bool isVolumetric() const { return material.volumetric != 0; }

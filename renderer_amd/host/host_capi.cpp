@@ -125,7 +125,7 @@ int mirth_set_textures(MirthScene* s, const float* tri_vt, int32_t n_textures, c
             return -1;
         }
     for (size_t o = 0; n_textures > 0 && o < sc.objectDescs.size(); o++)
-        for (int k : {object_tex[o].diffuse, object_tex[o].glossy_color, object_tex[o].glossy_coeff})
+        for (int k : {object_tex[o].diffuse, object_tex[o].glossy_color, object_tex[o].glossy_coeff, object_tex[o].bump})
             if (k < -1 || k >= n_textures) {
                 g_err = "mirth_set_textures: object_tex index out of range";
                 return -1;

@@ -163,7 +163,8 @@ void Scene::buildKDTree(bool upload) {
         ot.diffuse = addTexture(obj->diffuseTex);
         ot.glossy_color = addTexture(obj->glossyColorTex);
         ot.glossy_coeff = addTexture(obj->glossyCoeffTex);
-        ot.reserved = -1;
+        // SceneObject.cpp:253: the bump branch needs a texture of more than one texel and texture coordinates
+        ot.bump = obj->bumpTex && obj->bumpTex->size() > 1 && has_vt ? addTexture(obj->bumpTex) : -1;
         objectTex.push_back(ot);
         objTriangleOffsetMap.push_back(tri_offset);
         tri_offset += obj->getTriangleNum();

@@ -170,8 +170,8 @@ def test_textured_config_loads(ra, tmp_path):
     floor = r["objects"][6]
     assert set(np.unique(r["tri_vt"][floor["tri_begin"]:floor["tri_begin"] + 2])) == {0.0, 1.0}
     s.close()
-    # <colorTransform> sets the COORDINATE transform in the reference (Texture.cpp:154-155), kept; bump
-    # textures and unreadable files are refused
+    # <colorTransform> sets the COORDINATE transform in the reference (Texture.cpp:154-155), kept;
+    # unreadable files are refused
     mats = open(os.path.join(ROOT, "Data", "Materials.xml")).read()
     scene = open(os.path.join(ROOT, "Data", "Scene_Textured.xml")).read()
     for sub in ("objs", "textures"):
@@ -188,9 +188,81 @@ def test_textured_config_loads(ra, tmp_path):
     wall = r["textures"][r["object_tex"]["glossy_color"][7]]
     assert np.allclose(wall["coord"].diagonal(), (3, 3, 1, 1)) and np.allclose(wall["color"], np.eye(4))
     s.close()
-    (tmp_path / "Materials.xml").write_text(mats.replace("<type>Diffuse</type>\n\t<Texture>", "<type>Diffuse</type>\n\t<BumpTexture><path>textures/checker.pfm</path></BumpTexture>\n\t<Texture>"))
-    with pytest.raises(ra.MirtError, match="bump"):
-        ra.HostScene.load_config(str(tmp_path / "c.xml"))
     (tmp_path / "Materials.xml").write_text(mats.replace("textures/coeff.pfm", "textures/missing.pfm"))
     with pytest.raises(ra.MirtError, match="cannot open"):
         ra.HostScene.load_config(str(tmp_path / "c.xml"))
+
+
+def _bumped_floor(ra, texels, coord=None, color=None, vt_scale=1.0):
+    """floor_and_light whose floor carries a bump texture (texture coordinates as in _textured_floor)"""
+    m = meshgen.floor_and_light(albedo=0.6, emission=5.0)
+    s = ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"], m["objects"], m["tri_vn"])
+    v = m["verts"][m["tris"].astype(np.int64)]
+    vt = np.stack([(v[..., 0] + 20) / 40, (v[..., 2] + 20) / 40, np.zeros(v.shape[:2])], -1).reshape(len(v), 9) * vt_scale
+    ot = np.full(2, -1, ra.OBJECT_TEX_DTYPE)
+    ot["bump"][1] = 0
+    s.set_textures(vt.astype(np.float32), [ra.make_texture(texels, coord, color)], ot)
+    return s, m, vt.astype(np.float32)
+
+
+def test_bump_normal_known_answers(orc, ra):
+    """SceneObject::getWorldNormal's bump branch (SceneObject.cpp:250-283) and Texture::getGrad
+    (Texture.cpp:96-147) against the same formulas written out in float64 numpy."""
+    # a flat texture leaves the normal alone (zero gradient: angle 0)
+    s, m, vt = _bumped_floor(ra, np.full((4, 4), 0.5, np.float32))
+    S = orc.OracleScene(s.raw())
+    assert np.allclose(S.world_normal(2, (0.3, -1, 0.7)), (0, 1, 0), atol=1e-6)
+    S.close()
+    s.close()
+    # a ramp along u, read with a coordinate transform and a colour scale
+    ramp = np.tile(0.1 * np.arange(8, dtype=np.float32), (8, 1))
+    coord = np.diag([16.0, 16.0, 1, 1]).astype(np.float32)
+    color = np.diag([2.0, 2.0, 2.0, 1]).astype(np.float32)
+    s, m, vt = _bumped_floor(ra, ramp, coord, color)
+    S = orc.OracleScene(s.raw())
+    checked = 0
+    for tid in (2, 3):
+        vps = m["verts"][m["tris"][tid].astype(np.int64)].astype(np.float64)
+        vts = vt[tid].reshape(3, 3).astype(np.float64)
+        for p in ((0.3, -1, 0.7), (-1.2, -1, 0.4), (2.0, -1, -1.0), (-0.4, -1, -2.2)):
+            u = (p[0] + 20) / 40 * 16 * 8 - 0.5
+            if int(np.floor(u)) % 8 == 7:
+                continue  # the forward difference would wrap from the last texel to the first
+            g = np.array([0.1, 0.0, 0.0])                      # image gradient (right - left, top - bottom)
+            var_n = np.linalg.norm(g) * 2.0                      # through the colour transform
+            uvg = np.array([g[0] / np.linalg.norm(g) / 16, 0.0, var_n])  # direction through inverse(coordTransform)
+            b1, b2 = vps[1] - vps[0], vps[2] - vps[0]
+            d1, d2 = vts[1] - vts[0], vts[2] - vts[0]
+            k2 = (uvg[0] * d1[1] - uvg[1] * d1[0]) / (d1[1] * d2[0] - d1[0] * d2[1])
+            k1 = (uvg[1] - k2 * d2[1]) / d1[1]
+            dl = k1 * b1 / np.linalg.norm(b1) + k2 * b2 / np.linalg.norm(b2)
+            n = np.array([0.0, 1.0, 0.0])
+            dh = n * uvg[2]
+            if not np.isfinite(dl).all():
+                continue  # this triangle's first edge runs along u (duv1.y = 0): the reference divides by zero
+            ang = np.arctan2(np.linalg.norm(dh), np.linalg.norm(dl))
+            ax = np.cross(dl, dh)
+            ax /= np.linalg.norm(ax)
+            rot = n * np.cos(ang) + np.cross(ax, n) * np.sin(ang) + ax * np.dot(ax, n) * (1 - np.cos(ang))
+            got = S.world_normal(tid, p)
+            assert np.allclose(got, rot, atol=2e-4), (tid, p, got, rot)
+            assert abs(np.linalg.norm(got) - 1) < 1e-5 and got[1] < 0.999  # tilted, still unit length
+            checked += 1
+    assert checked >= 3
+    S.close()
+    s.close()
+
+
+def test_bump_config_loads(ra):
+    s = ra.HostScene.load_config(os.path.join(ROOT, "Data", "Config_Bump128.xml"))
+    r = s.raw()
+    ot = r["object_tex"]
+    assert [int(o["bump"]) >= 0 for o in ot] == [False, True, True, False, False, False, True, False]
+    for k in (1, 2, 6):
+        t = r["textures"][ot["bump"][k]]
+        assert t["texels"].shape == (16, 16)  # gray after ConfigManager.cpp:161's toGrayScale
+    assert np.allclose(r["textures"][ot["bump"][6]]["color"].diagonal(), (3, 3, 3, 1))
+    assert np.allclose(r["textures"][ot["bump"][2]]["coord"].diagonal(), (2, 2, 1, 1))
+    # the mean of the rgb texel (Texture.cpp:174)
+    assert abs(r["textures"][ot["bump"][1]]["texels"][0, 0] - 0.5 * (1 + 0.9 + 1.1) / 3) < 1e-6
+    s.close()
