@@ -216,7 +216,8 @@ def main():
             ks = json.load(open(tj))["kernels"]
             # one closest-hit call in the predicate mode = fast-tree launch + k_verify + exact re-run
             parts = [v for n, v in sorted(ks.items())
-                     if n.startswith("k_intersect<2, false, false") or n.startswith("k_verify<false, false")]
+                     if n.startswith("k_intersect<2, false, false, false, true") or n.startswith("k_verify<false, false")
+                     or n.startswith("k_rerun<false")]
             if parts:
                 traffic_bytes = int(sum(k["read_bytes"] + k["write_bytes"] for k in parts))
                 traffic_src = ("profiles/r1_current_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean per "
@@ -224,8 +225,8 @@ def main():
         out["roofline"] = {
             "bound": "hbm",
             "kernel": "one mirt_intersect_dev call in MODE_NO_SELF on the secondary batch (%d rays): k_intersect<NO_SELF, FAST> "
-                      "over the fast tree (the dominant launch, ~93 %% of kernel_ms) + k_verify + exact re-run of the "
-                      "rays it rejected" % n_sec,
+                      "over the fast tree (the dominant launch, ~90 %% of kernel_ms) + k_verify + k_rerun, the exact re-run "
+                      "of the rays it rejected, one wave per ray" % n_sec,
             "achieved": round(ach, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
