@@ -78,6 +78,9 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
 // not traversed at all (k_verify sends them to the exact kernel).
 // BUMP: the scene has bump textures (SceneObject.cpp:250-283): the predicate's normal is the perturbed one.
 // Only the NO_SELF instantiations differ; scenes without bump textures never run them.
+// ANYHIT + FAST: an occluder found in the fast tree's superset occludes if its chain of reference boxes
+// passes (k_verify); no occluder in the superset means none in the reference's set. The kernel leaves the
+// occluder's slot in id_out for k_verify; rejected rays are answered by the exact any-hit kernel.
 // ray_list != nullptr: the queue hands out positions of ray_list, which holds the ray indices (the
 // exact re-run of the rays k_verify rejected).
 #ifndef MIRT_WAVES_PER_EU
@@ -167,6 +170,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     auto accept = [&](float t, int s) {  // a legal candidate that beats the closest hit so far
         if (ANYHIT) {  // (only candidates nearer than the limit get here) one occluder is enough
             occluded = true;
+            best_slot = s;  // (FAST: k_verify checks this occluder's chain of reference boxes)
             has = false;
             return;
         }
@@ -342,6 +346,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         if (ANYHIT) {
             if (active && !has) {
                 vis_out[idx] = occluded ? 0 : 1;
+                // FAST: the occluder's slot, -1 for "nothing in the superset" (final), -2 for a ray given up
+                if (FAST) id_out[idx] = best_slot;
                 active = false;
             }
         } else if (active && !has) {

@@ -41,6 +41,8 @@ struct MirtContext {
     int* d_slot_node = nullptr;
     bool fast_tree = false;
     uint32_t* d_fb_list = nullptr;  // rays k_verify hands to the exact kernel
+    int* d_vis_slot = nullptr;      // visibility through the fast tree: occluder slot per ray, for k_verify
+    size_t vis_slot_cap = 0;
     size_t fb_cap = 0;
     DevLight* d_lights = nullptr;   // emission sampler tables (PathTracerTest)
     VtRec* d_vts = nullptr;          // textures: corner texture coordinates per slot, texture records, texel pool
@@ -61,7 +63,7 @@ struct MirtContext {
     ShadowBuf shb{};             // PathTracerTest: shadow rays of the running bounce
     size_t shb_cap = 0;
     uint32_t* d_ns = nullptr;    // [cnt_cap] shadow rays written by bounce k
-    uint32_t* d_wq2 = nullptr;   // [cnt_cap] ray-queue heads of the visibility launches
+    uint32_t* d_wq2 = nullptr;   // [3 * cnt_cap] queue words of the visibility launches (queue head, list length, queue head)
     uint32_t* d_cnt = nullptr;   // [cnt_cap] live paths after k bounces of the running wavefront
     uint32_t* d_wq = nullptr;    // [cnt_cap] ray-queue heads, one per intersect launch of the wavefront
     uint32_t* h_cnt = nullptr;   // pinned, [cnt_cap]
@@ -246,6 +248,7 @@ int mirt_destroy(MirtContext* ctx) {
     hipFree(ctx->d_counters);
     hipFree(ctx->d_queue);
     hipFree(ctx->d_fb_list);
+    hipFree(ctx->d_vis_slot);
     if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1020,6 +1023,19 @@ static int launch_mode(MirtContext* ctx, hipStream_t st, dim3 grid, dim3 block, 
     return MIRT_OK;
 }
 
+// list buffer of the fast path: one entry per ray of the largest batch so far
+static int ensure_fb_list(MirtContext* ctx, hipStream_t st, uint32_t n) {
+    if (n <= ctx->fb_cap) return MIRT_OK;  // (first use / a larger batch than any before: not on the timed path)
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->d_fb_list);
+    ctx->d_fb_list = nullptr;
+    ctx->fb_cap = 0;
+    HIPCHK(ctx, hipMalloc(&ctx->d_fb_list, (size_t)n * sizeof(uint32_t)));
+    ctx->fb_cap = n;
+    return MIRT_OK;
+}
+
 // Closest hit of n rays (n_ptr != nullptr: the count is read on the device, at most n). With the fast
 // tree: three launches, k_intersect<FAST> over the fast tree, k_verify (the winner's chain of reference
 // boxes, by the reference's test), and the exact kernel over the reference tree for the rays k_verify
@@ -1042,15 +1058,7 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
     if (exact_only || !ctx->fast_tree || mode != MIRT_MODE_NO_SELF)
         return launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out,
                                                    id_out, qwords, nullptr);
-    if (n > ctx->fb_cap) {  // (first use / a larger batch than any before: not on the timed path)
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        hipFree(ctx->d_fb_list);
-        ctx->d_fb_list = nullptr;
-        ctx->fb_cap = 0;
-        HIPCHK(ctx, hipMalloc(&ctx->d_fb_list, (size_t)n * sizeof(uint32_t)));
-        ctx->fb_cap = n;
-    }
+    if (ensure_fb_list(ctx, st, n) != MIRT_OK) return MIRT_E_HIP;
     int rc = launch_mode<COUNT, SLOT_OUT, true>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out, id_out,
                                                 qwords, nullptr);
     if (rc != MIRT_OK) return rc;
@@ -1078,7 +1086,9 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
     return rc;
 }
 
-// visibility variant: vis_out[i] = 1 unless a legal hit lies nearer than limit[i]
+// visibility variant: vis_out[i] = 1 unless a legal hit lies nearer than limit[i]. `queue`: THREE zeroed words
+// owned by this call (as in launch_intersect). In the predicate mode with a fast tree: any-hit walk of the
+// fast tree, k_verify on the occluders it found, exact any-hit kernel for the rays k_verify listed.
 static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
                              const int* aux, const float* limit, uint32_t n, uint32_t stride,
                              unsigned char* vis_out, const uint32_t* n_ptr = nullptr, uint32_t* queue = nullptr) {
@@ -1087,7 +1097,34 @@ static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const f
     dim3 block(ctx->block), grid(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks));
     if (!queue) {
         queue = ctx->d_queue;
-        HIPCHK(ctx, hipMemsetAsync(queue, 0, sizeof(uint32_t), st));
+        HIPCHK(ctx, hipMemsetAsync(queue, 0, 3 * sizeof(uint32_t), st));
+    }
+    static const bool vis_fast = !getenv("MIRT_VIS_FAST") || atoi(getenv("MIRT_VIS_FAST")) != 0;  // A/B switch
+    if (mode == MIRT_MODE_NO_SELF && ctx->fast_tree && vis_fast) {
+        int rc = ensure_fb_list(ctx, st, n);
+        if (rc != MIRT_OK) return rc;
+        if (n > ctx->vis_slot_cap) {
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(ctx->d_vis_slot);
+            ctx->d_vis_slot = nullptr;
+            ctx->vis_slot_cap = 0;
+            HIPCHK(ctx, hipMalloc(&ctx->d_vis_slot, (size_t)n * sizeof(int)));
+            ctx->vis_slot_cap = n;
+        }
+        hipLaunchKernelGGL((k_intersect<MIRT_MODE_NO_SELF, false, false, true, true>), grid, block, ctx->lds_main, st,
+                           ctx->sc, O, D, aux, n, n_ptr, stride, (float*)nullptr, ctx->d_vis_slot, ctx->d_counters, queue,
+                           ctx->lds_levels, ctx->d_spill, limit, vis_out);
+        HIPCHK(ctx, hipGetLastError());
+        hipLaunchKernelGGL((k_verify<true, false>), dim3(want), dim3(ctx->block), 0, st, ctx->sc, O, D, n, n_ptr, stride,
+                           (const float*)nullptr, ctx->d_vis_slot, ctx->d_fb_list, queue + 1, ctx->d_counters);
+        HIPCHK(ctx, hipGetLastError());
+        hipLaunchKernelGGL((k_intersect<MIRT_MODE_NO_SELF, false, false, true>), grid, block, ctx->lds_main, st, ctx->sc,
+                           O, D, aux, n, (const uint32_t*)(queue + 1), stride, (float*)nullptr, (int*)nullptr,
+                           ctx->d_counters, queue + 2, ctx->lds_levels, ctx->d_spill, limit, vis_out,
+                           (const uint32_t*)ctx->d_fb_list);
+        HIPCHK(ctx, hipGetLastError());
+        return MIRT_OK;
     }
 #define MIRT_VIS(MODE)                                                                                        \
     hipLaunchKernelGGL((k_intersect<MODE, false, false, true>), grid, block, ctx->lds_main, st, ctx->sc, O, D, aux, \
@@ -1407,13 +1444,13 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
         HIPCHK(ctx, hipMalloc(&ctx->d_cnt, words * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc(&ctx->d_wq, 3 * words * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc(&ctx->d_ns, words * sizeof(uint32_t)));
-        HIPCHK(ctx, hipMalloc(&ctx->d_wq2, words * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc(&ctx->d_wq2, 3 * words * sizeof(uint32_t)));
         HIPCHK(ctx, hipHostMalloc(&ctx->h_cnt, words * sizeof(uint32_t)));
         ctx->cnt_cap = words;
     }
     if (nee) {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_ns, 0, words * sizeof(uint32_t), st));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_wq2, 0, words * sizeof(uint32_t), st));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_wq2, 0, 3 * words * sizeof(uint32_t), st));
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_L, 0, 3 * ctx->pb_cap * sizeof(float), st));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt, 0, words * sizeof(uint32_t), st));
@@ -1449,7 +1486,7 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
                                ctx->shb, n_sh);
             HIPCHK(ctx, hipGetLastError());
             int rcv = launch_visibility(ctx, st, MIRT_MODE_NO_SELF, ctx->shb.o, ctx->shb.d, ctx->shb.ids, ctx->shb.lim,
-                                        bound, ctx->shb.stride, ctx->shb.vis, n_sh, ctx->d_wq2 + depth);
+                                        bound, ctx->shb.stride, ctx->shb.vis, n_sh, ctx->d_wq2 + 3 * depth);
             if (rcv != MIRT_OK) return rcv;
             hipLaunchKernelGGL(k_connect, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->shb, n_sh, bound, ctx->d_L,
                                (uint32_t)ctx->pb_cap);

@@ -250,6 +250,12 @@ def test_fast_path_fallbacks(gpu, cornell, cornell_oracle, mesh20k, mesh20k_orac
         tc, ic = S.intersect(o, d, aux, ra.MODE_NO_SELF, threads=16)
         assert np.array_equal(ig, ic) and np.array_equal(tg, tc)
         assert (ic >= 0).mean() > 0.3
+        # the any-hit query takes the same three-launch route (occluder from the fast tree, its chain
+        # verified, exact any-hit kernel for the rest): limits around, at and far from the true distance
+        lim = np.where(tc > 0, tc * rng.choice([0.5, 1.0, 1.0 + 2e-5, 1.5], n), 1.0).astype(np.float32)
+        vg = gpu.visibility(o, d, aux, lim, ra.MODE_NO_SELF)
+        vc = S.visibility(o, d, aux, lim, ra.MODE_NO_SELF, threads=16)
+        assert np.array_equal(vg, vc) and 0.2 < vc.mean() < 0.9
         # large batch, fast path against the exact kernel alone
         o2, d2, aux2 = meshgen.random_rays(1 << 21, 77, scene.n_objects, inside_obj=inside)
         o2[:, :n], d2[:, :n] = o, d
