@@ -1739,6 +1739,12 @@ void orc_texture_color(const OrcTexture* tex, const float coord[3], float out[3]
     const V3 c = textureColor(T, V3(coord[0], coord[1], coord[2]));
     out[0] = c.x, out[1] = c.y, out[2] = c.z;
 }
+// the matrix arithmetic of the texture path (nvMatrix.h:233-369, 415-424), for the known-answer tests
+void orc_mat_inverse(const float m[16], float out[16]) { invertMat(m, out); }
+void orc_mat_apply(const float m[16], const float v[3], float w, float out[3]) {
+    const V3 r = applyMat(m, V3(v[0], v[1], v[2]), w);
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
 void orc_tex_coord(const OrcScene* s, int32_t tid, const float pos[3], float out[3]) {
     const V3 c = texCoord(*s, (unsigned)tid, V3(pos[0], pos[1], pos[2]));
     out[0] = c.x, out[1] = c.y, out[2] = c.z;

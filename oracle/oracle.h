@@ -78,6 +78,9 @@ void orc_scene_set_textures(OrcScene* s, const float* tri_vt, int32_t n_textures
 /* Texture::getColor (Texture.cpp:43-94) and SimpleShape::getTexCoord (SimpleShape.cpp:274-298) */
 void orc_texture_color(const OrcTexture* tex, const float coord[3], float out[3]);
 void orc_tex_coord(const OrcScene* s, int32_t tid, const float pos[3], float out[3]);
+/* matrix4 inverse / matrix4 * vec4(v, w) as the texture path evaluates them (nvMatrix.h:233-369, 415-424) */
+void orc_mat_inverse(const float m[16], float out[16]);
+void orc_mat_apply(const float m[16], const float v[3], float w, float out[3]);
 
 /* tree facts + pre-order flatten (KDTree.cpp:346-383) */
 int32_t orc_tree_num_nodes(const OrcScene* s);

@@ -65,6 +65,27 @@ def test_oracle_normals_rotation_vectors(orc):
     assert (G["vec_normalize"][:3] == 0).all() and same(G["vec_div"][:16], G["vec_a"][:16])
 
 
+def test_oracle_matrix_ops(orc):
+    """the matrix arithmetic of the oracle's texture path (coordinate / colour transforms, the inverse
+    Texture::getGrad needs) against the reference's nvMatrix.h"""
+    L = orc.lib()
+    L.orc_mat_inverse.argtypes = [C.c_void_p] * 2
+    L.orc_mat_inverse.restype = None
+    L.orc_mat_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    L.orc_mat_apply.restype = None
+    n = len(G["xf_m"])
+    inv = np.zeros((n, 16), f32)
+    wv = np.zeros((n, 3), f32)
+    for i in range(n):
+        L.orc_mat_inverse(P(G["xf_m"][i].copy()), P(inv[i]))
+        L.orc_mat_apply(P(G["xf_m"][i].copy()), P(G["xf_v"][i].copy()), 1.0, P(wv[i]))
+    assert same(wv, G["xf_world_vertex"])
+    # a singular matrix: the reference returns identity when a row is all zero or the last pivot is 0, and
+    # otherwise whatever its elimination leaves; parity is required wherever its result is finite
+    ok = np.isfinite(G["xf_inverse"]).all(1)
+    assert ok.mean() > 0.9 and same(inv[ok], G["xf_inverse"][ok])
+
+
 def test_host_transforms(ra):
     """the product's host math (vecmath.h) that flattens a scene: world vertices and the normal matrix"""
     L = ra.lib()
