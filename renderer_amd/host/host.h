@@ -76,8 +76,8 @@ public:
 class ConfigManager;
 
 // Texture.h:14-42 — an image (.pfm only, as in the reference: Texture.cpp:5-41) with a coordinate and a
-// colour transform. The lookups run on the device (mirt_dev.h tex_color); this class loads, holds and
-// describes the data, and keeps getColor for host-side checks.
+// colour transform. The lookups run on the device (mirt_dev.h tex_color / tex_grad); this class loads, holds and
+// describes the data.
 class Texture {
 public:
     bool hasColor = true;
@@ -96,7 +96,6 @@ public:
     }
     void toGrayScale();                                  // Texture.cpp:164-176
     int size() const { return width * height; }
-    vec3f getColor(const vec3f& coord) const;            // Texture.cpp:43-94
     void loadTextureFromXML(const ConfigManager* cm, XmlNode* nodeTex);  // Texture.cpp:149-162
     MirtTexture describe() const;                        // pointers stay valid while the texture lives
 };

@@ -1,8 +1,10 @@
 // texture.cpp — Texture (Texture.h:14-42, Texture.cpp:5-176) on the host: file loading, XML and the
-// description handed to the device. The lookups that matter run in mirt_dev.h (tex_color); getColor
-// here is the same arithmetic for host-side checks.
+// description handed to the device. The lookups themselves (Texture::getColor / getGrad) run on the
+// device only: mirt_dev.h tex_color / tex_grad.
+#include <cctype>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -10,41 +12,67 @@
 
 namespace mirt_host {
 
-// Texture::loadFile (Texture.cpp:5-41): ".pfm" only, "PF" = rgb / "Pf" = gray, texels kept in file order,
-// the scale / endianness field read and ignored, one byte (two after a CR) between header and data.
-// Any other extension leaves the texture as it was, like the reference.
+// Texture::loadFile (Texture.cpp:5-41) accepts only names ending in "pfm" and leaves the texture untouched
+// otherwise. Header as that loader consumes it: "P", one type character ('F' rgb, 'f' gray), two integers,
+// one real (scale / endianness: read, ignored), then exactly one byte, or two when the first is a carriage
+// return; the texels follow as raw fp32 in file order (no flip, no byte swap).
+namespace {
+struct PfmCursor {
+    const std::vector<unsigned char>& buf;
+    size_t at = 0;
+    explicit PfmCursor(const std::vector<unsigned char>& b) : buf(b) {}
+    void skipSpace() {
+        while (at < buf.size() && isspace(buf[at])) at++;
+    }
+    bool number(double& out) {  // what fscanf's %d / %f would take after optional white space
+        skipSpace();
+        const char* begin = reinterpret_cast<const char*>(buf.data()) + at;
+        char* end = nullptr;
+        out = strtod(begin, &end);
+        if (end == begin) return false;
+        at += (size_t)(end - begin);
+        return true;
+    }
+};
+}  // namespace
+
 void Texture::loadFile(const std::string& fileName) {
-    if (fileName.size() < 3 || fileName.substr(fileName.size() - 3, 3) != "pfm") return;
-    FILE* file = fopen(fileName.c_str(), "rb");
-    if (!file) throw std::runtime_error("Texture: cannot open " + fileName);
-    char c = 0;
-    int w = 0, h = 0;
-    float form = 0.f;
-    bool ok = fscanf(file, "P%c", &c) == 1 && (c == 'f' || c == 'F') && fscanf(file, "%d %d", &w, &h) == 2 &&
-              w > 0 && h > 0 && (long long)w * h <= (1ll << 28) && fscanf(file, "%f", &form) == 1;
-    if (ok) {
-        hasColor = c == 'F';
-        ok = fread(&c, 1, 1, file) == 1;
-        if (ok && c == 0x0D) ok = fread(&c, 1, 1, file) == 1;
+    const size_t L = fileName.size();
+    if (L < 3 || fileName.compare(L - 3, 3, "pfm") != 0) return;
+    std::vector<unsigned char> bytes;
+    {
+        FILE* f = fopen(fileName.c_str(), "rb");
+        if (!f) throw std::runtime_error("Texture: cannot open " + fileName);
+        unsigned char chunk[1 << 16];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof chunk, f)) > 0) bytes.insert(bytes.end(), chunk, chunk + got);
+        fclose(f);
     }
-    if (ok) {
-        width = w;
-        height = h;
-        const size_t n = (size_t)w * h;
-        if (hasColor) {
-            std::vector<float> raw(3 * n);
-            ok = fread(raw.data(), sizeof(float), raw.size(), file) == raw.size();
-            colors.resize(n);
-            values.clear();
-            for (size_t i = 0; i < n; i++) colors[i] = vec3f(raw[3 * i], raw[3 * i + 1], raw[3 * i + 2]);
-        } else {
-            values.resize(n);
-            colors.clear();
-            ok = fread(values.data(), sizeof(float), n, file) == n;
-        }
+    bytes.push_back(0);  // terminator for strtod
+    const std::runtime_error bad("Texture: " + fileName + " is not a readable .pfm");
+    if (bytes.size() < 4 || bytes[0] != 'P' || (bytes[1] != 'F' && bytes[1] != 'f')) throw bad;
+    const bool rgb = bytes[1] == 'F';
+    PfmCursor cur(bytes);
+    cur.at = 2;
+    double w = 0, h = 0, scale = 0;
+    if (!cur.number(w) || !cur.number(h) || !cur.number(scale)) throw bad;
+    if (w < 1 || h < 1 || w != floor(w) || h != floor(h) || w * h > double(1 << 28)) throw bad;
+    cur.at += (cur.at < bytes.size() && bytes[cur.at] == 0x0D) ? 2 : 1;
+    const size_t count = (size_t)w * (size_t)h, floats = count * (rgb ? 3 : 1);
+    if (cur.at + floats * sizeof(float) > bytes.size() - 1) throw bad;
+    std::vector<float> raw(floats);
+    memcpy(raw.data(), bytes.data() + cur.at, floats * sizeof(float));
+    hasColor = rgb;
+    width = (int)w;
+    height = (int)h;
+    colors.clear();
+    values.clear();
+    if (rgb) {
+        colors.reserve(count);
+        for (size_t k = 0; k < count; k++) colors.emplace_back(raw[3 * k], raw[3 * k + 1], raw[3 * k + 2]);
+    } else {
+        values.swap(raw);
     }
-    fclose(file);
-    if (!ok) throw std::runtime_error("Texture: " + fileName + " is not a readable .pfm");
 }
 
 // Texture.cpp:164-176
@@ -57,41 +85,6 @@ void Texture::toGrayScale() {
     values.resize(colors.size());
     for (size_t i = 0; i < colors.size(); i++) values[i] = (colors[i].x + colors[i].y + colors[i].z) / 3;
     colors.clear();
-}
-
-// Texture.cpp:43-94 (the gray branch reads its fourth texel at (top, left), Texture.cpp:86)
-vec3f Texture::getColor(const vec3f& coord) const {
-    vec3f tc = coordTransform.apply(coord, 1.f);
-    float u = tc.x * width - 0.5;
-    float v = tc.y * height - 0.5;
-    int left = (int)floor(u);
-    int right = left + 1;
-    int bottom = (int)floor(v);
-    int top = bottom + 1;
-    u -= left;
-    v -= bottom;
-    left %= width;
-    right %= width;
-    top %= height;
-    bottom %= height;
-    if (left < 0) left += width;
-    if (right < 0) right += width;
-    if (top < 0) top += height;
-    if (bottom < 0) bottom += height;
-    if (hasColor) {
-        vec3f color(0, 0, 0);
-        color = color + colors[bottom * width + left] * (1 - u) * (1 - v);
-        color = color + colors[bottom * width + right] * u * (1 - v);
-        color = color + colors[top * width + left] * (1 - u) * v;
-        color = color + colors[top * width + right] * u * v;
-        return colorTransform.apply(color, 1.f);
-    }
-    float color = 0;
-    color += values[bottom * width + left] * (1 - u) * (1 - v);
-    color += values[bottom * width + right] * u * (1 - v);
-    color += values[top * width + left] * (1 - u) * v;
-    color += values[top * width + left] * u * v;
-    return colorTransform.apply(vec3f(color, color, color), 1.f);
 }
 
 // Texture.cpp:149-162. <colorTransform> sets the COORDINATE transform there (Texture.cpp:154-155 call
