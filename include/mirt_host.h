@@ -66,6 +66,16 @@ int mirth_fill_intersect(MirthScene* s, size_t n, const float* o, const float* d
  * connected (Ray::intersectDist there) -> visible[n] (1 = unoccluded, MCRenderer.cpp:115-117 rule) */
 int mirth_test_visibility(MirthScene* s, size_t n, const float* o, const float* d, const int32_t* contact,
                           const int32_t* inside, const float* dist, uint8_t* visible);
+/* MCRenderer::testPathListVisibility (MCRenderer.cpp:520-570) on flattened path lists: path pair p owns start
+ * vertices [start_off[p], start_off[p+1]) and end vertices [end_off[p], end_off[p+1]); per vertex its origin
+ * [*,3] and whether its direction is RANDOM (1) or DEFINITE (0); start vertices also their contact / inside object
+ * ids (-1 = NULL). bits_off[p] (n_paths + 1 entries, filled here) gives the first 32-bit word of pair p in
+ * bits[]; bit j * |end| + k of a pair = connection (start j, end k) unoccluded. bits_capacity in words.       */
+int mirth_test_path_list_visibility(MirthScene* s, int32_t n_paths, const int32_t* start_off, const float* start_o,
+                                    const int32_t* start_contact, const int32_t* start_inside,
+                                    const uint8_t* start_random, const int32_t* end_off, const float* end_o,
+                                    const uint8_t* end_random, int32_t* bits_off, uint32_t* bits,
+                                    size_t bits_capacity);
 /* Host math used while flattening a scene: transform * (v,1) (SimpleShape.h:46) and
  * transpose(inverse(transform)) * (vn,0) (SimpleShape.cpp:310,322); m[r*4+c] = element(r,c). */
 void mirth_world_vertex(const float m[16], const float v[3], float out[3]);

@@ -90,7 +90,7 @@ MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_s
                 "mirt_render_pt_dev", "mirt_render_pttest", "mirt_render_pttest_dev", "mirt_capture_rays_dev", "mirt_device_info"]
 MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_set_textures", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
-                 "mirth_describe", "mirth_upload", "mirth_render", "mirth_render_progressive", "mirth_fill_intersect", "mirth_test_visibility", "mirth_world_vertex", "mirth_normal_transform",
+                 "mirth_describe", "mirth_upload", "mirth_render", "mirth_render_progressive", "mirth_fill_intersect", "mirth_test_visibility", "mirth_test_path_list_visibility", "mirth_world_vertex", "mirth_normal_transform",
                  "mirth_shutdown",
                  "mirth_save_pfm", "mirth_load_pfm"]
 
@@ -160,6 +160,7 @@ def lib():
         L.mirth_render_progressive.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_char_p, C.c_char_p,
                                                C.c_void_p, C.POINTER(RenderStats)]
         L.mirth_test_visibility.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
+        L.mirth_test_path_list_visibility.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 10 + [C.c_size_t]
         L.mirth_world_vertex.argtypes = [C.c_void_p] * 3
         L.mirth_world_vertex.restype = None
         L.mirth_normal_transform.argtypes = [C.c_void_p] * 3
@@ -341,6 +342,38 @@ class HostScene:
                                        _ptr(vis)) != 0:
             raise MirtError(lib().mirth_last_error().decode())
         return vis
+
+
+def _path_list_visibility(self, start_paths, end_paths):
+    """MCRenderer::testPathListVisibility. start_paths[p]: dict(o [n,3], contact [n], inside [n], random [n]);
+    end_paths[p]: dict(o [m,3], random [m]). Returns a list of bool arrays [n, m]."""
+    P = len(start_paths)
+    assert P == len(end_paths)
+    def cat(L, k, dt):
+        w = 3 if k == "o" else 1
+        parts = [np.asarray(x[k], dt).reshape(-1, w) for x in L]
+        return np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros((0, w), dt))
+    so, eo = cat(start_paths, "o", np.float32), cat(end_paths, "o", np.float32)
+    sc, si = cat(start_paths, "contact", np.int32), cat(start_paths, "inside", np.int32)
+    sr, er = cat(start_paths, "random", np.uint8), cat(end_paths, "random", np.uint8)
+    soff = np.concatenate([[0], np.cumsum([len(x["o"]) for x in start_paths])]).astype(np.int32)
+    eoff = np.concatenate([[0], np.cumsum([len(x["o"]) for x in end_paths])]).astype(np.int32)
+    words = int(sum((len(a["o"]) * len(b["o"]) + 31) // 32 for a, b in zip(start_paths, end_paths)))
+    bits = np.zeros(max(words, 1), np.uint32)
+    boff = np.zeros(P + 1, np.int32)
+    if lib().mirth_test_path_list_visibility(self.h, P, _ptr(soff), _ptr(so), _ptr(sc), _ptr(si), _ptr(sr), _ptr(eoff),
+                                             _ptr(eo), _ptr(er), _ptr(boff), _ptr(bits), len(bits)) != 0:
+        raise MirtError(lib().mirth_last_error().decode())
+    out = []
+    for p, (a, b) in enumerate(zip(start_paths, end_paths)):
+        n, m = len(a["o"]), len(b["o"])
+        w = bits[boff[p]:boff[p + 1]]
+        flat = ((w[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1)[:n * m].astype(bool)
+        out.append(flat.reshape(n, m))
+    return out
+
+
+HostScene.test_path_list_visibility = _path_list_visibility
 
 
 def save_pfm(path, img):

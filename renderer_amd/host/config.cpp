@@ -295,6 +295,45 @@ bool MCRenderer::testVisibility(const Ray& startRay, const Ray& endRay) {
     return renderer->scene.testVisibility(one)[0];
 }
 
+// MCRenderer::testPathListVisibility (MCRenderer.cpp:520-570)
+std::vector<std::vector<unsigned>> MCRenderer::testPathListVisibility(const std::vector<Path>& startPathList,
+                                                                      const std::vector<Path>& endPathList) {
+    if (startPathList.size() != endPathList.size())
+        throw std::runtime_error("testPathListVisibility: the two lists must pair up");
+    std::vector<std::vector<unsigned>> bits(startPathList.size());
+    auto connectable = [](const Ray& a, const Ray& b) {
+        return a.directionSampleType == Ray::RANDOM && b.directionSampleType == Ray::RANDOM;
+    };
+    std::vector<Ray> batch;
+    size_t first = 0;  // first path pair whose connections are in `batch`
+    for (size_t i = 0; i < startPathList.size(); i++) {
+        const Path& sp = startPathList[i];
+        const Path& ep = endPathList[i];
+        bits[i].assign((sp.size() * ep.size() + 31) / 32, 0u);
+        for (const Ray& a : sp)
+            for (const Ray& b : ep) {
+                if (!connectable(a, b)) continue;
+                Ray v = a;
+                v.direction = b.origin - a.origin;
+                v.intersectDist = v.direction.length();
+                v.direction.normalize();
+                batch.push_back(v);
+            }
+        if (batch.size() <= 1024 * 1024 && i + 1 != startPathList.size()) continue;
+        const std::vector<bool> vis = renderer->scene.testVisibility(batch);
+        size_t next = 0;
+        for (size_t p = first; p <= i; p++) {
+            const size_t ne = endPathList[p].size(), total = startPathList[p].size() * ne;
+            for (size_t q = 0; q < total; q++)
+                if (connectable(startPathList[p][q / ne], endPathList[p][q % ne]) && vis[next++])
+                    bits[p][q / 32] |= 1u << (q % 32);
+        }
+        first = i + 1;
+        batch.clear();
+    }
+    return bits;
+}
+
 // MCRenderer.cpp:500-518: "PF\nW H\n-1.000000\n", rows bottom-to-top, channels R,G,B, little-endian
 void MCRenderer::saveImagePFM(const std::string& fileName, const std::vector<vec3f>& pixels, int w, int h) {
     FILE* f = fopen(fileName.c_str(), "wb");

@@ -25,6 +25,8 @@ class SceneObject;
 // Ray.h:8-61 — the fields the batched GPU path reads or fills
 class Ray {
 public:
+    enum SampleType { RANDOM, DEFINITE };  // Ray.h:11
+    SampleType directionSampleType = RANDOM, originSampleType = DEFINITE;  // Ray.h:44-46 defaults
     vec3f origin;
     vec3f direction;  // terminated if length < 0.5 (Ray.h:16)
     vec3f color;
@@ -239,6 +241,12 @@ public:
     virtual std::vector<vec3f> renderPixels(const Camera& camera);
     // MCRenderer::testVisibility (MCRenderer.cpp:106-118), a one-ray batch on the device
     bool testVisibility(const Ray& startRay, const Ray& endRay);
+    // MCRenderer::testPathListVisibility (MCRenderer.cpp:520-570): for every pair of paths, one bit per
+    // (start vertex j, end vertex k) at index j * |end| + k, set when both vertices have RANDOM directions and
+    // the segment between them is unoccluded; the connections go to the device in batches of > 2^20 rays
+    typedef std::vector<Ray> Path;
+    std::vector<std::vector<unsigned>> testPathListVisibility(const std::vector<Path>& startPathList,
+                                                              const std::vector<Path>& endPathList);
     // PFM writer with the reference's layout (MCRenderer.cpp:500-518)
     void setOutputIter(int n) { outputIter = n; }
     int getOutputIter() const { return outputIter; }

@@ -336,6 +336,49 @@ int mirth_test_visibility(MirthScene* s, size_t n, const float* o, const float* 
     })
 }
 
+int mirth_test_path_list_visibility(MirthScene* s, int32_t n_paths, const int32_t* start_off, const float* start_o,
+                                    const int32_t* start_contact, const int32_t* start_inside,
+                                    const uint8_t* start_random, const int32_t* end_off, const float* end_o,
+                                    const uint8_t* end_random, int32_t* bits_off, uint32_t* bits,
+                                    size_t bits_capacity) {
+    if (!s || n_paths < 0 || !start_off || !start_o || !start_random || !end_off || !end_o || !end_random ||
+        !bits_off || !bits)
+        return -1;
+    GUARD({
+        Scene& sc = s->renderer.scene;
+        if (sc.objects.empty()) throw std::runtime_error("mirth_test_path_list_visibility: needs a scene loaded from a config");
+        if (!s->renderer.mcRenderer) throw std::runtime_error("mirth_test_path_list_visibility: the config names no renderer");
+        std::vector<MCRenderer::Path> sp(n_paths), ep(n_paths);
+        for (int32_t p = 0; p < n_paths; p++) {
+            for (int32_t i = start_off[p]; i < start_off[p + 1]; i++) {
+                Ray r;
+                r.origin = vec3f(start_o[3 * i], start_o[3 * i + 1], start_o[3 * i + 2]);
+                const int c = start_contact ? start_contact[i] : -1, in = start_inside ? start_inside[i] : -1;
+                if (c >= (int)sc.objects.size() || in >= (int)sc.objects.size())
+                    throw std::runtime_error("mirth_test_path_list_visibility: object id out of range");
+                r.contactObject = c >= 0 ? sc.objects[c] : nullptr;
+                r.insideObject = in >= 0 ? sc.objects[in] : nullptr;
+                r.directionSampleType = start_random[i] ? Ray::RANDOM : Ray::DEFINITE;
+                sp[p].push_back(r);
+            }
+            for (int32_t i = end_off[p]; i < end_off[p + 1]; i++) {
+                Ray r;
+                r.origin = vec3f(end_o[3 * i], end_o[3 * i + 1], end_o[3 * i + 2]);
+                r.directionSampleType = end_random[i] ? Ray::RANDOM : Ray::DEFINITE;
+                ep[p].push_back(r);
+            }
+        }
+        const std::vector<std::vector<unsigned>> v = s->renderer.mcRenderer->testPathListVisibility(sp, ep);
+        size_t at = 0;
+        for (int32_t p = 0; p < n_paths; p++) {
+            bits_off[p] = (int32_t)at;
+            if (at + v[p].size() > bits_capacity) throw std::runtime_error("mirth_test_path_list_visibility: bits_capacity too small");
+            for (unsigned w : v[p]) bits[at++] = w;
+        }
+        bits_off[n_paths] = (int32_t)at;
+    })
+}
+
 // the host math layer, exposed so tests can pin it against the reference's own headers
 void mirth_world_vertex(const float m[16], const float v[3], float out[3]) {
     matrix4 M;

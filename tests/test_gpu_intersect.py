@@ -484,3 +484,50 @@ def test_visibility_between_path_vertices(cornell, cornell_oracle, ra):
         vg = cornell.test_visibility(a, d, c, i, dist)
         vc = cornell_oracle.visibility(a.T.copy(), d.T.copy(), ra.pack_ids(c, i), dist, ra.MODE_NO_SELF, threads=16)
         assert np.array_equal(vg, vc)
+
+
+def test_path_list_visibility(cornell, cornell_oracle, ra):
+    """MCRenderer::testPathListVisibility (MCRenderer.cpp:520-570) through the host surface: every
+    (start vertex, end vertex) pair of each path pair whose two vertices have RANDOM directions, one bit
+    each, against per-connection oracle queries; DEFINITE vertices leave their bits 0; ragged and empty
+    paths"""
+    cornell.upload()
+    cam = cornell.camera()
+    rng = np.random.default_rng(12)
+    starts, ends = [], []
+    for pixel in range(0, 128 * 128, 31):
+        va, _, na = cornell_oracle.trace_path(cam, pixel, 4)
+        vb, _, nb = cornell_oracle.trace_path(cam, (pixel * 7 + 13) % (128 * 128), 5)
+        pa = np.array([v[:3] for v in va[1:min(na, len(va))]], np.float32).reshape(-1, 3)
+        pb = np.array([v[:3] for v in vb[1:min(nb, len(vb))]], np.float32).reshape(-1, 3)
+        starts.append(dict(o=pa, contact=rng.choice([-1, 3, 6], len(pa)).astype(np.int32),
+                           inside=np.full(len(pa), -1, np.int32), random=(rng.random(len(pa)) < 0.8).astype(np.uint8)))
+        ends.append(dict(o=pb, random=(rng.random(len(pb)) < 0.8).astype(np.uint8)))
+    starts.append(dict(o=np.zeros((0, 3), np.float32), contact=np.zeros(0, np.int32), inside=np.zeros(0, np.int32),
+                       random=np.zeros(0, np.uint8)))
+    ends.append(dict(o=np.array([[0, 0, 0]], np.float32), random=np.ones(1, np.uint8)))
+    got = cornell.test_path_list_visibility(starts, ends)
+    assert len(got) == len(starts) and got[-1].shape == (0, 1)
+    checked = 0
+    for a, b, g in zip(starts, ends, got):
+        n, m = len(a["o"]), len(b["o"])
+        assert g.shape == (n, m)
+        if n == 0 or m == 0:
+            continue
+        jj, kk = np.meshgrid(np.arange(n), np.arange(m), indexing="ij")
+        jj, kk = jj.ravel(), kk.ravel()
+        both = (a["random"][jj] != 0) & (b["random"][kk] != 0)
+        assert not g.ravel()[~both].any()
+        if not both.any():
+            continue
+        o = a["o"][jj[both]]
+        seg = b["o"][kk[both]] - o
+        # (direction and length as MCRenderer.cpp:541-544 form them: fp32 difference, length, normalize)
+        dist = np.sqrt((seg[:, 0] * seg[:, 0] + seg[:, 1] * seg[:, 1]) + seg[:, 2] * seg[:, 2]).astype(np.float32)
+        ok = dist > 0
+        d = np.where(ok[:, None], seg / np.where(ok, dist, 1)[:, None], seg).astype(np.float32)
+        aux = ra.pack_ids(a["contact"][jj[both]], a["inside"][jj[both]])
+        vc = cornell_oracle.visibility(o.T.copy(), d.T.copy(), aux, dist, ra.MODE_NO_SELF, threads=16)
+        assert np.array_equal(g.ravel()[both], vc.astype(bool))
+        checked += int(both.sum())
+    assert checked > 2000  # connections compared
