@@ -86,8 +86,13 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
 #ifndef MIRT_WAVES_PER_EU
 #define MIRT_WAVES_PER_EU 5
 #endif
+#ifndef MIRT_WAVES_PER_EU_FAST
+#define MIRT_WAVES_PER_EU_FAST 6
+#endif
 template <int MODE, bool COUNT, bool SLOT_OUT, bool ANYHIT = false, bool FAST = false, bool BUMP = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_WAVES_PER_EU, MIRT_WAVES_PER_EU)))
+__global__ void __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(FAST && !COUNT ? MIRT_WAVES_PER_EU_FAST : MIRT_WAVES_PER_EU,
+                                   FAST && !COUNT ? MIRT_WAVES_PER_EU_FAST : MIRT_WAVES_PER_EU)))
 k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ D,
             const int* __restrict__ aux, uint32_t n_direct, const uint32_t* __restrict__ n_ptr,
             uint32_t plane_stride, float* __restrict__ t_out,

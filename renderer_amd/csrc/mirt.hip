@@ -55,6 +55,10 @@ struct MirtContext {
     int block = 256;
     size_t lds_main = 0;   // the first lds_levels stack levels live in LDS, deeper ones in d_spill
     uint32_t lds_levels = 0;
+    // the same three for the fast-tree instantiations, which are built for more waves per SIMD
+    size_t lds_main_fast = 0;
+    uint32_t lds_levels_fast = 0;
+    int max_blocks_fast = 0;
     uint2* d_spill = nullptr;
     // wavefront path state
     PathBuf pb[2]{};
@@ -953,28 +957,41 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     // pushes (rare: the stack holds the far siblings of the current path, a handful) go to a global
     // spill area.
     ctx->block = 256;
-    hipFuncAttributes fa{};
-    int by_regs = 4;
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_intersect<MIRT_MODE_NO_SELF, false, false>)) == hipSuccess &&
-        fa.numRegs > 0)
-        by_regs = std::max(1, std::min(8, 512 / ((fa.numRegs + 7) / 8 * 8)));  // waves per SIMD
     const int waves_per_block = std::max(1, ctx->block / 64);
-    const int want_blocks = std::max(1, by_regs * 4 / waves_per_block);
-    size_t lds_budget = (size_t)160 * 1024 / want_blocks;
-    uint32_t levels = (uint32_t)std::min<size_t>((size_t)depth + 1, std::max<size_t>(4, lds_budget / (8 * (size_t)ctx->block)));
-    if (const char* e = getenv("MIRT_LDS_LEVELS")) levels = (uint32_t)std::min<long>(depth + 1, std::max<long>(1, atol(e)));
-    ctx->lds_levels = levels;
-    ctx->lds_main = (size_t)levels * 8 * ctx->block;
-    // persistent grid: as many blocks as stay resident (a larger grid would only queue; smaller
-    // batches launch fewer). The occupancy answer is advisory, nothing waits on co-residency.
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_intersect<MIRT_MODE_NO_SELF, false, false>,
-                                                     ctx->block, ctx->lds_main) != hipSuccess || occ < 1)
-        occ = 1;
-    ctx->max_blocks = occ * ctx->n_cus;
-    const size_t spill_levels = (size_t)depth + 1 - levels;
-    if (spill_levels)
-        HIPCHK(ctx, hipMalloc(&ctx->d_spill, spill_levels * (size_t)ctx->max_blocks * ctx->block * sizeof(uint2)));
+    auto size_launch = [&](const void* fn, size_t* lds_main, uint32_t* lds_levels, int* max_blocks) {
+        hipFuncAttributes fa{};
+        int by_regs = 4;
+        if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0)
+            by_regs = std::max(1, std::min(8, 512 / ((fa.numRegs + 7) / 8 * 8)));  // waves per SIMD
+        const int want_blocks = std::max(1, by_regs * 4 / waves_per_block);
+        const size_t lds_budget = (size_t)160 * 1024 / want_blocks;
+        uint32_t levels = (uint32_t)std::min<size_t>((size_t)depth + 1, std::max<size_t>(4, lds_budget / (8 * (size_t)ctx->block)));
+        if (const char* e = getenv("MIRT_LDS_LEVELS")) levels = (uint32_t)std::min<long>(depth + 1, std::max<long>(1, atol(e)));
+        *lds_levels = levels;
+        *lds_main = (size_t)levels * 8 * ctx->block;
+        // persistent grid: as many blocks as stay resident (a larger grid would only queue; smaller
+        // batches launch fewer). The occupancy answer is advisory, nothing waits on co-residency.
+        *max_blocks = want_blocks * ctx->n_cus;  // (refined by the occupancy query below)
+    };
+    size_launch(reinterpret_cast<const void*>(&k_intersect<MIRT_MODE_NO_SELF, false, false>), &ctx->lds_main,
+                &ctx->lds_levels, &ctx->max_blocks);
+    size_launch(reinterpret_cast<const void*>(&k_intersect<MIRT_MODE_NO_SELF, false, false, false, true>),
+                &ctx->lds_main_fast, &ctx->lds_levels_fast, &ctx->max_blocks_fast);
+    {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_intersect<MIRT_MODE_NO_SELF, false, false>, ctx->block,
+                                                         ctx->lds_main) == hipSuccess && occ >= 1)
+            ctx->max_blocks = occ * ctx->n_cus;
+        occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_intersect<MIRT_MODE_NO_SELF, false, false, false, true>,
+                                                         ctx->block, ctx->lds_main_fast) == hipSuccess && occ >= 1)
+            ctx->max_blocks_fast = occ * ctx->n_cus;
+    }
+    // one spill area serves both configurations (launches on a handle do not overlap)
+    const size_t spill_a = ((size_t)depth + 1 - ctx->lds_levels) * (size_t)ctx->max_blocks;
+    const size_t spill_b = ((size_t)depth + 1 - ctx->lds_levels_fast) * (size_t)ctx->max_blocks_fast;
+    if (std::max(spill_a, spill_b))
+        HIPCHK(ctx, hipMalloc(&ctx->d_spill, std::max(spill_a, spill_b) * ctx->block * sizeof(uint2)));
     ctx->has_scene = true;
     ctx->has_media = n_vpm > 0;
     ctx->media_ready = media_ready;
@@ -995,6 +1012,13 @@ static void launch_pair(MirtContext* ctx, hipStream_t st, dim3 grid, dim3 block,
                                ctx->lds_levels, ctx->d_spill, (const float*)nullptr, (unsigned char*)nullptr, ray_list);
             return;
         }
+    }
+    if constexpr (FAST) {  // built for more waves per SIMD: its own grid and LDS share
+        const dim3 g(std::min<uint32_t>((n + block.x - 1) / block.x, (uint32_t)ctx->max_blocks_fast));
+        hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT, false, true>), g, block, ctx->lds_main_fast, st, ctx->sc, O,
+                           D, aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue, ctx->lds_levels_fast,
+                           ctx->d_spill, (const float*)nullptr, (unsigned char*)nullptr, ray_list);
+        return;
     }
     hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT, false, FAST>), grid, block, ctx->lds_main, st, ctx->sc, O, D,
                        aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue, ctx->lds_levels, ctx->d_spill,
@@ -1112,9 +1136,10 @@ static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const f
             HIPCHK(ctx, hipMalloc(&ctx->d_vis_slot, (size_t)n * sizeof(int)));
             ctx->vis_slot_cap = n;
         }
-        hipLaunchKernelGGL((k_intersect<MIRT_MODE_NO_SELF, false, false, true, true>), grid, block, ctx->lds_main, st,
+        const dim3 gfast(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks_fast));
+        hipLaunchKernelGGL((k_intersect<MIRT_MODE_NO_SELF, false, false, true, true>), gfast, block, ctx->lds_main_fast, st,
                            ctx->sc, O, D, aux, n, n_ptr, stride, (float*)nullptr, ctx->d_vis_slot, ctx->d_counters, queue,
-                           ctx->lds_levels, ctx->d_spill, limit, vis_out);
+                           ctx->lds_levels_fast, ctx->d_spill, limit, vis_out);
         HIPCHK(ctx, hipGetLastError());
         hipLaunchKernelGGL((k_verify<true, false>), dim3(want), dim3(ctx->block), 0, st, ctx->sc, O, D, n, n_ptr, stride,
                            (const float*)nullptr, ctx->d_vis_slot, ctx->d_fb_list, queue + 1, ctx->d_counters);
