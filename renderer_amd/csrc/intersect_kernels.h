@@ -87,7 +87,7 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
 #define MIRT_WAVES_PER_EU 5
 #endif
 #ifndef MIRT_WAVES_PER_EU_FAST
-#define MIRT_WAVES_PER_EU_FAST 6
+#define MIRT_WAVES_PER_EU_FAST 7
 #endif
 template <int MODE, bool COUNT, bool SLOT_OUT, bool ANYHIT = false, bool FAST = false, bool BUMP = false>
 __global__ void __launch_bounds__(256)
@@ -108,8 +108,14 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     const uint32_t bs = blockDim.x;
     // per-lane stack, [level][lane] of (child link, entry distance): the first
     // lds_levels levels in LDS, deeper ones (rarely reached) in the global spill area
-    uint2* stk = (uint2*)lds + threadIdx.x;
-    uint2* stk_deep = spill + ((size_t)blockIdx.x * bs + threadIdx.x);
+    // (address spaces spelled out: a generic pointer chosen between the two at run time costs an aperture test
+    // per access, and trips this compiler's verifier at 7 waves per SIMD)
+    // (entries move as one 64-bit scalar, link | entry distance << 32: a vector type would be copied through a
+    // generic reference and bring the generic pointer back)
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    typedef __attribute__((address_space(1))) unsigned long long glb_u64;
+    lds_u64* stk = (lds_u64*)lds + threadIdx.x;
+    glb_u64* stk_deep = (glb_u64*)spill + ((size_t)blockIdx.x * bs + threadIdx.x);
     const size_t deep_stride = (size_t)gridDim.x * bs;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -166,7 +172,14 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         has = false;
         while (sp > 0) {
             sp--;
-            const uint2 e = (uint32_t)sp < lds_levels ? stk[sp * bs] : stk_deep[(sp - lds_levels) * deep_stride];
+            // (two loads in two address spaces, on purpose: a select between the pointers would go through a
+            // generic pointer, and its aperture test trips this compiler at higher occupancy targets)
+            unsigned long long packed;
+            if ((uint32_t)sp < lds_levels)
+                packed = stk[sp * bs];
+            else
+                packed = stk_deep[(sp - lds_levels) * deep_stride];
+            const uint2 e = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
             if (__uint_as_float(e.y) > thr) continue;
             enter((int)e.x);
             break;
@@ -281,7 +294,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             const int kl = __float_as_int(P.lb.z), kr = __float_as_int(P.rb.z);
             const bool pick_l = vl & (!vr | (lbl <= lbr));  // nearer child first
             if (vl & vr) {
-                const uint2 e = make_uint2((uint32_t)(pick_l ? kr : kl), __float_as_uint(pick_l ? lbr : lbl));
+                const unsigned long long e = (unsigned long long)(uint32_t)(pick_l ? kr : kl) |
+                                             ((unsigned long long)__float_as_uint(pick_l ? lbr : lbl) << 32);
                 if ((uint32_t)sp < lds_levels)
                     stk[sp * bs] = e;
                 else
