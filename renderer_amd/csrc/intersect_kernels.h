@@ -42,7 +42,11 @@ namespace mirt {
 #endif
 constexpr uint32_t RAY_CHUNK = MIRT_RAY_CHUNK;  // rays a wave reserves per queue atomic
 constexpr int FAST_AMBIGUOUS_BUDGET = 16;  // k_intersect<FAST>: unproven boxes a ray may enter before it is handed to the exact kernel
-constexpr int LEAF_BATCH = MIRT_LEAF_BATCH;     // triangles a lane tests per leaf phase before the wave regroups
+#ifndef MIRT_LEAF_BATCH_FAST
+#define MIRT_LEAF_BATCH_FAST 6
+#endif
+// triangles a lane tests per leaf phase before the wave regroups (exact kernels / fast-tree kernels: swept separately)
+constexpr int LEAF_BATCH_EXACT = MIRT_LEAF_BATCH, LEAF_BATCH_FAST = MIRT_LEAF_BATCH_FAST;
 
 struct Audit {
     unsigned long long box = 0, tri = 0, amb = 0, bad = 0, walk = 0;
@@ -101,6 +105,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             const float* __restrict__ limit = nullptr, unsigned char* __restrict__ vis_out = nullptr,
             const uint32_t* __restrict__ ray_list = nullptr) {
     extern __shared__ uint32_t lds[];
+    constexpr int LEAF_BATCH = FAST ? LEAF_BATCH_FAST : LEAF_BATCH_EXACT;
     const PairRec* __restrict__ pairs = FAST ? sc.fpairs : sc.pairs;
     const float4 root_lo = FAST ? sc.froot_lo : sc.root_lo, root_hi = FAST ? sc.froot_hi : sc.root_hi;
     // ray count: given, or (wavefront path tracer) left in device memory by the previous shade pass
