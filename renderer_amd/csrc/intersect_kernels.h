@@ -87,6 +87,9 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
 // occluder's slot in id_out for k_verify; rejected rays are answered by the exact any-hit kernel.
 // ray_list != nullptr: the queue hands out positions of ray_list, which holds the ray indices (the
 // exact re-run of the rays k_verify rejected).
+#ifndef MIRT_BLOCK
+#define MIRT_BLOCK 256  // lanes per block of the traversal kernels (swept: 128 / 256 / 512)
+#endif
 #ifndef MIRT_WAVES_PER_EU
 #define MIRT_WAVES_PER_EU 5
 #endif
@@ -94,7 +97,7 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
 #define MIRT_WAVES_PER_EU_FAST 7
 #endif
 template <int MODE, bool COUNT, bool SLOT_OUT, bool ANYHIT = false, bool FAST = false, bool BUMP = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(MIRT_BLOCK)
 __attribute__((amdgpu_waves_per_eu(FAST && !COUNT ? MIRT_WAVES_PER_EU_FAST : MIRT_WAVES_PER_EU,
                                    FAST && !COUNT ? MIRT_WAVES_PER_EU_FAST : MIRT_WAVES_PER_EU)))
 k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ D,

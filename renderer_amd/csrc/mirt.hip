@@ -956,7 +956,7 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     // levels live in LDS as still let the register-limited number of blocks stay resident; deeper
     // pushes (rare: the stack holds the far siblings of the current path, a handful) go to a global
     // spill area.
-    ctx->block = 256;
+    ctx->block = MIRT_BLOCK;
     const int waves_per_block = std::max(1, ctx->block / 64);
     auto size_launch = [&](const void* fn, size_t* lds_main, uint32_t* lds_levels, int* max_blocks) {
         hipFuncAttributes fa{};
@@ -1086,7 +1086,7 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
     int rc = launch_mode<COUNT, SLOT_OUT, true>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out, id_out,
                                                 qwords, nullptr);
     if (rc != MIRT_OK) return rc;
-    hipLaunchKernelGGL((k_verify<SLOT_OUT, COUNT>), dim3(want), dim3(ctx->block), 0, st, ctx->sc, O, D, n, n_ptr, stride,
+    hipLaunchKernelGGL((k_verify<SLOT_OUT, COUNT>), dim3((n + 255) / 256), dim3(256), 0, st, ctx->sc, O, D, n, n_ptr, stride,
                        (const float*)t_out, id_out, ctx->d_fb_list, qwords + 1, ctx->d_counters);
     HIPCHK(ctx, hipGetLastError());
     // the listed rays, by the reference arithmetic on the reference tree: one wave per ray (k_rerun); the
@@ -1141,7 +1141,7 @@ static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const f
                            ctx->sc, O, D, aux, n, n_ptr, stride, (float*)nullptr, ctx->d_vis_slot, ctx->d_counters, queue,
                            ctx->lds_levels_fast, ctx->d_spill, limit, vis_out);
         HIPCHK(ctx, hipGetLastError());
-        hipLaunchKernelGGL((k_verify<true, false>), dim3(want), dim3(ctx->block), 0, st, ctx->sc, O, D, n, n_ptr, stride,
+        hipLaunchKernelGGL((k_verify<true, false>), dim3((n + 255) / 256), dim3(256), 0, st, ctx->sc, O, D, n, n_ptr, stride,
                            (const float*)nullptr, ctx->d_vis_slot, ctx->d_fb_list, queue + 1, ctx->d_counters);
         HIPCHK(ctx, hipGetLastError());
         hipLaunchKernelGGL((k_intersect<MIRT_MODE_NO_SELF, false, false, true>), grid, block, ctx->lds_main, st, ctx->sc,
