@@ -477,11 +477,11 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
 // (l >> 1), surviving inner children are pushed back, a lane whose child is a leaf tests its triangles.
 // No distance pruning: the answer is the plain definition, argmin over { legal triangle hits whose every
 // ancestor box passes box_test } in the order (t, later leaf link, earlier slot) of the header comment,
-// so the visit order is free. NO_SELF predicate only (the fast path serves that mode alone).
+// so the visit order is free.
 // Stack bound: batch steps (pop k <= 32, push <= 2k) only while sp <= CAP - 192, single-pair depth-first
 // steps above that, which add at most depth + 1 (<= MIRT_MAX_TREE_DEPTH + 1) entries.
 constexpr int RERUN_STACK = 2048;
-template <bool SLOT_OUT>
+template <bool SLOT_OUT, int MODE = MIRT_MODE_NO_SELF>
 __global__ void __launch_bounds__(64)
 k_rerun(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, const int* __restrict__ aux,
         uint32_t plane_stride, float* __restrict__ t_out, int* __restrict__ id_out,
@@ -494,7 +494,7 @@ k_rerun(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, c
         const uint32_t idx = list[r];
         const f3 o = mk3(O[idx], O[plane_stride + idx], O[2 * plane_stride + idx]);
         const f3 d = mk3(D[idx], D[plane_stride + idx], D[2 * plane_stride + idx]);
-        const int a = aux[idx];
+        const int a = MODE != MIRT_MODE_UNCONDITIONAL ? aux[idx] : 0;
         const int contact = unpack_contact(a), inside = unpack_inside(a);
         float best = 0.f;
         int best_slot = -1, best_leaf = -1;
@@ -520,9 +520,13 @@ k_rerun(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, c
                     const float t = tri_test(T, o, d);
                     if (!(t >= 0.f)) continue;
                     if (!(best_slot < 0 || t < best || (t == best && best_leaf < beg))) continue;
-                    const VnRec V = sc.vns[s];
-                    const f3 nn = shading_normal<false>(sc, T, V, s, o + d * t);
-                    if (!legal_noself(dot3(d, nn), __float_as_int(V.n0.w), contact, inside)) continue;
+                    if (MODE == MIRT_MODE_NO_SELF) {
+                        const VnRec V = sc.vns[s];
+                        const f3 nn = shading_normal<false>(sc, T, V, s, o + d * t);
+                        if (!legal_noself(dot3(d, nn), __float_as_int(V.n0.w), contact, inside)) continue;
+                    } else if (MODE == MIRT_MODE_LAST_TID) {
+                        if (__float_as_int(sc.vns[s].n1.w) == a) continue;
+                    }
                     best = t;
                     best_slot = s;
                     best_leaf = beg;

@@ -50,6 +50,7 @@ struct MirtContext {
     float* d_texels = nullptr;
     DevBump* d_bumps = nullptr;
     bool has_bump = false;
+    bool fast_all_modes = false;    // modes 0 / 1 through the fast tree too (large scenes)
     float* d_light_area = nullptr;
     int* d_light_slot = nullptr;
     int block = 256;
@@ -894,6 +895,11 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     ctx->sc.rnodes = ctx->d_rnodes;
     ctx->sc.slot_node = ctx->d_slot_node;
     ctx->fast_tree = use_fast;
+    // Modes 0 / 1 (coherent camera rays, as a rule): on the Cornell scene the reference tree alone is faster
+    // (0.89 vs 0.98 ms per 4 Mi rays: verify + re-run cost more than the shorter walk saves), on the 1 M-triangle
+    // scene the fast tree is (1.99 -> 1.57 ms): the walk is what waits for memory there.
+    ctx->fast_all_modes = N >= 100000;
+    if (const char* e = getenv("MIRT_FAST_ALL_MODES")) ctx->fast_all_modes = atoi(e) != 0;  // A/B switch
     ctx->sc.vols = ctx->d_vols;
     ctx->sc.n_vols = n_obj_trees;
     if (!lights.empty()) {
@@ -1077,9 +1083,9 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
         qwords = ctx->d_queue;
         HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
     }
-    // camera rays (mode 0) are coherent and measured faster on the reference tree alone (0.94 vs 1.07 ms
-    // for the 4 Mi Cornell batch): the fast path serves the predicate mode, where the rays are incoherent
-    if (exact_only || !ctx->fast_tree || mode != MIRT_MODE_NO_SELF)
+    // the fast path serves the predicate mode (incoherent rays) and, on large scenes, the other two as well
+    // (ctx->fast_all_modes, set at upload)
+    if (exact_only || !ctx->fast_tree || (mode != MIRT_MODE_NO_SELF && !ctx->fast_all_modes))
         return launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out,
                                                    id_out, qwords, nullptr);
     if (ensure_fb_list(ctx, st, n) != MIRT_OK) return MIRT_E_HIP;
@@ -1093,8 +1099,15 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
     // instrumented call keeps the one-lane-per-ray kernel, whose counters the audit reads
     static const bool rerun_wide = !getenv("MIRT_RERUN_WIDE") || atoi(getenv("MIRT_RERUN_WIDE")) != 0;  // A/B switch
     if (!COUNT && rerun_wide) {
-        hipLaunchKernelGGL((k_rerun<SLOT_OUT>), dim3(std::min<uint32_t>(n, 1024)), dim3(64), 0, st, ctx->sc, O, D, aux,
-                           stride, t_out, id_out, (const uint32_t*)ctx->d_fb_list, (const uint32_t*)(qwords + 1));
+        const dim3 rg(std::min<uint32_t>(n, 1024)), rb(64);
+        const uint32_t* list = ctx->d_fb_list;
+        const uint32_t* count = qwords + 1;
+        if (mode == MIRT_MODE_NO_SELF)
+            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_NO_SELF>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count);
+        else if (mode == MIRT_MODE_LAST_TID)
+            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_LAST_TID>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count);
+        else
+            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_UNCONDITIONAL>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count);
         HIPCHK(ctx, hipGetLastError());
     } else {
         rc = launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, qwords + 1, stride, t_out,

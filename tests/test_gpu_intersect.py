@@ -267,6 +267,30 @@ def test_fast_path_fallbacks(gpu, cornell, cornell_oracle, mesh20k, mesh20k_orac
         assert np.array_equal(i1, i0) and np.array_equal(t1, t0)
 
 
+def test_fast_path_other_modes(gpu, cornell, cornell_oracle, mesh20k, mesh20k_oracle, ra, monkeypatch):
+    """Large scenes send modes 0 and 1 through the fast tree as well (k_rerun<…, MODE> answers the rejected
+    rays); forced on here for the small scenes, against the oracle bit for bit, adversarial rays included"""
+    monkeypatch.setenv("MIRT_FAST_ALL_MODES", "1")
+    for scene, S in ((cornell, cornell_oracle), (mesh20k, mesh20k_oracle)):
+        gpu.upload(scene.describe())
+        n = 100000
+        o, d = _adversarial_rays(scene, n, 17)
+        o2, d2, _ = meshgen.random_rays(300000, 18, scene.n_objects)
+        o, d = np.concatenate([o, o2], 1), np.concatenate([d, d2], 1)
+        last = np.random.default_rng(19).integers(-1, scene.n_tris, o.shape[1]).astype(np.int32)
+        for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_LAST_TID, last)):
+            tg, ig = gpu.intersect(o, d, a, mode)
+            tc, ic = S.intersect(o, d, a, mode, threads=16)
+            assert np.array_equal(ig, ic) and np.array_equal(tg, tc), mode
+        # make the hit triangle itself the excluded one: mode 1 must then find the next hit
+        t0, i0 = S.intersect(o, d, None, ra.MODE_UNCONDITIONAL, threads=16)
+        tg, ig = gpu.intersect(o, d, i0, ra.MODE_LAST_TID)
+        tc, ic = S.intersect(o, d, i0, ra.MODE_LAST_TID, threads=16)
+        assert np.array_equal(ig, ic) and np.array_equal(tg, tc) and (ic != i0)[i0 >= 0].all()
+    monkeypatch.delenv("MIRT_FAST_ALL_MODES")
+    gpu.upload(cornell.describe())
+
+
 def test_classifier_audit(gpu, cornell, mesh20k, cornell_oracle, ra):
     """Every box decision the slab classifier claims to have PROVEN is re-evaluated with the exact
     reference test inside the instrumented kernel: zero disagreements over millions of rays, incl.
