@@ -201,7 +201,10 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* scene);
  * t_out: float[n]; tid_out: int32[n] global triangle id or -1. Host pointers.                */
 int mirt_intersect(MirtContext* ctx, const float* origins, const float* directions,
                    const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out);
-/* Same with DEVICE pointers; asynchronous on `stream` (a hipStream_t, NULL = context stream). */
+/* Same with DEVICE pointers; asynchronous on `stream` (a hipStream_t, NULL = context stream). Two first-use
+ * exceptions synchronise the stream once: a batch larger than any before (a list buffer grows), and, in modes
+ * 0 / 1, the first batch of >= 2^18 rays on a scene (both traversal paths are run and timed, the faster one is
+ * kept for that scene and mode; MIRT_FAST_ALL_MODES=0/1 in the environment fixes the choice instead).       */
 int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* directions,
                        const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
                        void* stream);

@@ -51,6 +51,17 @@ struct MirtContext {
     DevBump* d_bumps = nullptr;
     bool has_bump = false;
     bool fast_all_modes = false;    // modes 0 / 1 through the fast tree too (large scenes)
+    // modes 0 / 1 on smaller scenes: which path is faster depends on the rays (camera inside or outside the
+    // geometry ...), so the first large call of a mode runs BOTH paths, times them and keeps the faster one for the
+    // scene (one extra launch and one stream synchronisation, once per scene and mode; both paths return the same
+    // answers). state: 0 untimed, 3 decided.
+    struct PathTune {
+        int state = 0;
+        bool use_fast = false;
+        double exact_ns_per_ray = 0, fast_ns_per_ray = 0;
+        hipEvent_t a = nullptr, b = nullptr, c = nullptr;
+    } tune[2];
+    bool tune_modes = true;
     float* d_light_area = nullptr;
     int* d_light_slot = nullptr;
     int block = 256;
@@ -252,6 +263,12 @@ int mirt_destroy(MirtContext* ctx) {
     hipFree(ctx->d_wq2);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_queue);
+    for (auto& t : ctx->tune) {
+        if (t.a) hipEventDestroy(t.a);
+        if (t.b) hipEventDestroy(t.b);
+        if (t.c) hipEventDestroy(t.c);
+        t.a = t.b = t.c = nullptr;
+    }
     hipFree(ctx->d_fb_list);
     hipFree(ctx->d_vis_slot);
     if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
@@ -899,7 +916,12 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     // (0.89 vs 0.98 ms per 4 Mi rays: verify + re-run cost more than the shorter walk saves), on the 1 M-triangle
     // scene the fast tree is (1.99 -> 1.57 ms): the walk is what waits for memory there.
     ctx->fast_all_modes = N >= 100000;
-    if (const char* e = getenv("MIRT_FAST_ALL_MODES")) ctx->fast_all_modes = atoi(e) != 0;  // A/B switch
+    ctx->tune_modes = true;
+    if (const char* e = getenv("MIRT_FAST_ALL_MODES")) {  // A/B switch: forces either way, no timing
+        ctx->fast_all_modes = atoi(e) != 0;
+        ctx->tune_modes = false;
+    }
+    for (auto& t : ctx->tune) t.state = 0, t.use_fast = false;
     ctx->sc.vols = ctx->d_vols;
     ctx->sc.n_vols = n_obj_trees;
     if (!lights.empty()) {
@@ -1083,11 +1105,36 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
         qwords = ctx->d_queue;
         HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
     }
-    // the fast path serves the predicate mode (incoherent rays) and, on large scenes, the other two as well
-    // (ctx->fast_all_modes, set at upload)
-    if (exact_only || !ctx->fast_tree || (mode != MIRT_MODE_NO_SELF && !ctx->fast_all_modes))
-        return launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out,
-                                                   id_out, qwords, nullptr);
+    // the fast path serves the predicate mode (incoherent rays), on large scenes the other two as well
+    // (ctx->fast_all_modes, set at upload), and on the rest whichever path the first large calls showed faster
+    bool use_fast = !exact_only && ctx->fast_tree && (mode == MIRT_MODE_NO_SELF || ctx->fast_all_modes);
+    MirtContext::PathTune* timed = nullptr;
+    if (!COUNT && !exact_only && ctx->fast_tree && !ctx->fast_all_modes && ctx->tune_modes &&
+        (mode == MIRT_MODE_UNCONDITIONAL || mode == MIRT_MODE_LAST_TID)) {
+        MirtContext::PathTune& T = ctx->tune[mode];
+        if (T.state == 3) {
+            use_fast = T.use_fast;
+        } else if (!n_ptr && n >= (1u << 18)) {
+            if (!T.a && (hipEventCreate(&T.a) != hipSuccess || hipEventCreate(&T.b) != hipSuccess ||
+                         hipEventCreate(&T.c) != hipSuccess)) {
+                T.state = 3;  // no events: stay on the reference tree
+            } else {  // the reference tree first (timed here), then fall through to the fast path (timed below)
+                HIPCHK(ctx, hipEventRecord(T.a, st));
+                const int rc0 = launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride,
+                                                                    t_out, id_out, qwords, nullptr);
+                if (rc0 != MIRT_OK) return rc0;
+                HIPCHK(ctx, hipEventRecord(T.b, st));
+                HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
+                use_fast = true;
+                timed = &T;
+            }
+        }
+    }
+    if (!use_fast) {
+        const int rc0 = launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out,
+                                                            id_out, qwords, nullptr);
+        return rc0;
+    }
     if (ensure_fb_list(ctx, st, n) != MIRT_OK) return MIRT_E_HIP;
     int rc = launch_mode<COUNT, SLOT_OUT, true>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out, id_out,
                                                 qwords, nullptr);
@@ -1119,6 +1166,21 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
         hipStreamSynchronize(st);
         hipMemcpy(h, qwords, sizeof(h), hipMemcpyDeviceToHost);
         fprintf(stderr, "[mirt] fast path: %u rays, %u re-run on the reference tree\n", n, h[1]);
+    }
+    if (timed && rc == MIRT_OK) {
+        HIPCHK(ctx, hipEventRecord(timed->c, st));
+        HIPCHK(ctx, hipEventSynchronize(timed->c));
+        float ms_exact = 0.f, ms_fast = 0.f;
+        if (hipEventElapsedTime(&ms_exact, timed->a, timed->b) == hipSuccess &&
+            hipEventElapsedTime(&ms_fast, timed->b, timed->c) == hipSuccess) {
+            timed->exact_ns_per_ray = (double)ms_exact * 1e6 / n;
+            timed->fast_ns_per_ray = (double)ms_fast * 1e6 / n;
+            timed->use_fast = ms_fast < 0.97f * ms_exact;
+            if (getenv("MIRT_DEBUG_TUNE"))
+                fprintf(stderr, "[mirt] mode %d: reference tree %.3f ns/ray, fast tree %.3f ns/ray -> %s\n", mode,
+                        timed->exact_ns_per_ray, timed->fast_ns_per_ray, timed->use_fast ? "fast tree" : "reference tree");
+        }
+        timed->state = 3;
     }
     return rc;
 }
