@@ -1109,12 +1109,12 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
     // (ctx->fast_all_modes, set at upload), and on the rest whichever path the first large calls showed faster
     bool use_fast = !exact_only && ctx->fast_tree && (mode == MIRT_MODE_NO_SELF || ctx->fast_all_modes);
     MirtContext::PathTune* timed = nullptr;
-    if (!COUNT && !exact_only && ctx->fast_tree && !ctx->fast_all_modes && ctx->tune_modes &&
+    if (!exact_only && ctx->fast_tree && !ctx->fast_all_modes && ctx->tune_modes &&
         (mode == MIRT_MODE_UNCONDITIONAL || mode == MIRT_MODE_LAST_TID)) {
         MirtContext::PathTune& T = ctx->tune[mode];
         if (T.state == 3) {
-            use_fast = T.use_fast;
-        } else if (!n_ptr && n >= (1u << 18)) {
+            use_fast = T.use_fast;  // (the instrumented calls follow the choice, they never make it)
+        } else if (!COUNT && !n_ptr && n >= (1u << 18)) {
             if (!T.a && (hipEventCreate(&T.a) != hipSuccess || hipEventCreate(&T.b) != hipSuccess ||
                          hipEventCreate(&T.c) != hipSuccess)) {
                 T.state = 3;  // no events: stay on the reference tree
