@@ -37,11 +37,28 @@ namespace mirt {
 #ifndef MIRT_RAY_CHUNK
 #define MIRT_RAY_CHUNK 64
 #endif
+#ifndef MIRT_RAY_CHUNK_COHERENT
+#define MIRT_RAY_CHUNK_COHERENT 256
+#endif
+#ifndef MIRT_RAY_CHUNK_INCOHERENT
+#define MIRT_RAY_CHUNK_INCOHERENT 128
+#endif
+#ifndef MIRT_RAY_CHUNK_MIN_RAYS
+#define MIRT_RAY_CHUNK_MIN_RAYS (1u << 20)
+#endif
 #ifndef MIRT_LEAF_BATCH
 #define MIRT_LEAF_BATCH 8
 #endif
-constexpr uint32_t RAY_CHUNK = MIRT_RAY_CHUNK;  // rays a wave reserves per queue atomic
-constexpr int FAST_AMBIGUOUS_BUDGET = 16;  // k_intersect<FAST>: unproven boxes a ray may enter before it is handed to the exact kernel
+// Rays a wave reserves per queue atomic. A wave refills idle lanes from its current chunk, so the chunk size is
+// also how far apart in the batch the rays of one wave lie: camera rays (modes 0 / 1, neighbours in the batch are
+// neighbours on the screen) gain from long chunks (4 Mi Cornell camera rays: 0.89 ms at 64, 0.66 at 128, 0.63 at
+// 256, 0.74 at 512), bounce rays barely (3.70 / 3.68 / 3.76 / 4.07 ms). Small launches keep 64 so that every wave
+// of the grid gets work.
+constexpr uint32_t RAY_CHUNK_SMALL = MIRT_RAY_CHUNK;
+#ifndef MIRT_FAST_BUDGET
+#define MIRT_FAST_BUDGET 16
+#endif
+constexpr int FAST_AMBIGUOUS_BUDGET = MIRT_FAST_BUDGET;  // k_intersect<FAST>: unproven boxes a ray may enter before it is handed to the exact kernel
 #ifndef MIRT_LEAF_BATCH_FAST
 #define MIRT_LEAF_BATCH_FAST 6
 #endif
@@ -114,6 +131,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     // ray count: given, or (wavefront path tracer) left in device memory by the previous shade pass
     const uint32_t n = n_ptr ? min(*n_ptr, n_direct) : n_direct;
     const uint32_t bs = blockDim.x;
+    const uint32_t RAY_CHUNK = n < MIRT_RAY_CHUNK_MIN_RAYS ? RAY_CHUNK_SMALL
+                               : (MODE == MIRT_MODE_NO_SELF ? MIRT_RAY_CHUNK_INCOHERENT : MIRT_RAY_CHUNK_COHERENT);
     // per-lane stack, [level][lane] of (child link, entry distance): the first
     // lds_levels levels in LDS, deeper ones (rarely reached) in the global spill area
     // (address spaces spelled out: a generic pointer chosen between the two at run time costs an aperture test
