@@ -93,6 +93,14 @@ k_generate(DevCamera cam, uint32_t n, uint32_t spp_begin, uint32_t seed, float* 
     if (i >= n) return;
     uint32_t wh = (uint32_t)cam.width * (uint32_t)cam.height;
     uint32_t pixel = i % wh, sample = spp_begin + i / wh;
+    // The wavefront path tracer's own camera pass walks the image in 16 x 16 tiles (256 consecutive rays = one
+    // tile = one ray chunk of a traversal wave, intersect_kernels.h): neighbours in the batch are neighbours on
+    // the screen in both directions. Sample streams and radiance slots are keyed by (pixel, sample), so the
+    // image does not depend on this order. The public ray generator (fill_state 0) keeps the documented one.
+    if (fill_state && (cam.width & 15) == 0 && (cam.height & 15) == 0) {
+        const uint32_t tile = pixel >> 8, within = pixel & 255u, tiles_x = (uint32_t)cam.width >> 4;
+        pixel = ((tile / tiles_x) * 16u + (within >> 4)) * (uint32_t)cam.width + (tile % tiles_x) * 16u + (within & 15u);
+    }
     uint32_t key = stream_key(seed, pixel, sample), ctr = 0;
     float u = rng_float(key, ctr);
     float v = rng_float(key, ctr);
@@ -112,7 +120,7 @@ k_generate(DevCamera cam, uint32_t n, uint32_t spp_begin, uint32_t seed, float* 
         pb.key[i] = key;
         pb.ctr[i] = ctr;
         pb.ids[i] = MIRT_PACK_IDS(-1, -1);
-        pb.pid[i] = i;
+        pb.pid[i] = (i / wh) * wh + pixel;  // sample_local * W*H + pixel, whatever the order of the batch
     }
 }
 
