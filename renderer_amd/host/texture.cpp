@@ -75,15 +75,14 @@ void Texture::loadFile(const std::string& fileName) {
     }
 }
 
-// Texture.cpp:164-176
+// Texture::toGrayScale (Texture.cpp:164-176): one channel per texel, the plain mean of r, g, b; a texture that
+// already holds gray values keeps them (and drops any rgb copy).
 void Texture::toGrayScale() {
     hasColor = false;
-    if (colors.empty() || !values.empty()) {
-        colors.clear();
-        return;
+    if (values.empty() && !colors.empty()) {
+        values.reserve(colors.size());
+        for (const vec3f& c : colors) values.push_back((c.x + c.y + c.z) / 3);
     }
-    values.resize(colors.size());
-    for (size_t i = 0; i < colors.size(); i++) values[i] = (colors[i].x + colors[i].y + colors[i].z) / 3;
     colors.clear();
 }
 
