@@ -21,6 +21,15 @@ so = torch.empty((3, cap), dtype=torch.float32, device="cuda"); sd = torch.empty
 sa = torch.empty(cap, dtype=torch.int32, device="cuda"); torch.cuda.synchronize()
 dev.generate_rays_dev(cam, 0, 4, 1, po.data_ptr(), pd.data_ptr())
 n_sec = dev.capture_rays_dev(cam, 12, 1, 3, so.data_ptr(), sd.data_ptr(), sa.data_ptr(), cap)
+if os.environ.get("SORT"):  # experiment: what a coherence reorder of the bounce batch would buy
+    d_ = sd[:, :n_sec]; o_ = so[:, :n_sec]
+    key = ((d_[0] < 0).to(torch.int64) | ((d_[1] < 0).to(torch.int64) << 1) | ((d_[2] < 0).to(torch.int64) << 2))
+    if os.environ["SORT"] == "octant_cell":
+        q = ((o_.clamp(-1, 1) + 1) * 3.999).to(torch.int64)  # 8^3 origin cells
+        key = key * 512 + (q[0] * 64 + q[1] * 8 + q[2])
+    perm = torch.sort(key, stable=True).indices
+    so[:, :n_sec] = o_[:, perm]; sd[:, :n_sec] = d_[:, perm]; sa[:n_sec] = sa[:n_sec][perm]
+    torch.cuda.synchronize()
 t1 = torch.empty(cap, dtype=torch.float32, device="cuda"); i1 = torch.empty(cap, dtype=torch.int32, device="cuda")
 ts = torch.cuda.Stream(); st = C.c_void_p(ts.cuda_stream); torch.cuda.synchronize()
 def run(o, d, a, n, mode):
