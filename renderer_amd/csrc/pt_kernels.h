@@ -551,6 +551,9 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
 // emitter hit is weighted against the light connection that could have found it, and every RANDOM
 // vertex writes one shadow ray + its pending contribution to `sh` (compacted like the paths); the
 // visibility launch and k_connect finish it. Scenes without media only (checked on the host).
+#ifndef MIRT_SHADE_OCTANT
+#define MIRT_SHADE_OCTANT 1
+#endif
 template <bool VOL, bool NEE = false>
 __global__ void __launch_bounds__(256)
 k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_in, uint32_t n_max,
@@ -769,8 +772,20 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
     // ---- compaction: ballot inside the wave, prefix over the block's waves, one atomic per block
     const unsigned long long m = __ballot(alive);
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+    uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) s_wcnt[w] = __popcll(m);
+#if MIRT_SHADE_OCTANT
+    // survivors of a block leave ordered by the octant of their new direction: the next traversal's waves
+    // (which take consecutive rays) then hold rays that agree on the order in which children are visited
+    __shared__ uint32_t s_oct[4][8];
+    const int oct = (nd.x < 0.f ? 1 : 0) | (nd.y < 0.f ? 2 : 0) | (nd.z < 0.f ? 4 : 0);
+    uint32_t in_wave_before = 0;
+    for (int k = 0; k < 8; k++) {
+        const unsigned long long mk = __ballot(alive && oct == k);
+        if (lane == 0) s_oct[w][k] = __popcll(mk);
+        if (k == oct) in_wave_before = __popcll(mk & ((1ull << lane) - 1ull));
+    }
+#endif
     const unsigned long long m2 = NEE ? __ballot(shadow) : 0ull;
     if (NEE && lane == 0) s_wcnt2[w] = __popcll(m2);
     __syncthreads();
@@ -796,7 +811,13 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
     }
     if (alive) {
         uint32_t wb = 0;
+#if MIRT_SHADE_OCTANT
+        for (int k = 0; k < oct; k++) wb += s_oct[0][k] + s_oct[1][k] + s_oct[2][k] + s_oct[3][k];
+        for (uint32_t k = 0; k < w; k++) wb += s_oct[k][oct];
+        rank = in_wave_before;
+#else
         for (uint32_t k = 0; k < w; k++) wb += s_wcnt[k];
+#endif
         const uint32_t j = s_base + wb + rank;
         store3(out.o, out.stride, j, no);
         store3(out.d, out.stride, j, nd);
