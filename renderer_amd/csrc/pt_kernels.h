@@ -9,6 +9,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MIRT_TILE_MORTON
+#define MIRT_TILE_MORTON 1
+#endif
+
 namespace mirt {
 
 // SoA path state; planes have `stride` elements. Hit fields (t, slot) are filled by k_intersect.
@@ -99,7 +103,19 @@ k_generate(DevCamera cam, uint32_t n, uint32_t spp_begin, uint32_t seed, float* 
     // image does not depend on this order. The public ray generator (fill_state 0) keeps the documented one.
     if (fill_state && (cam.width & 15) == 0 && (cam.height & 15) == 0) {
         const uint32_t tile = pixel >> 8, within = pixel & 255u, tiles_x = (uint32_t)cam.width >> 4;
-        pixel = ((tile / tiles_x) * 16u + (within >> 4)) * (uint32_t)cam.width + (tile % tiles_x) * 16u + (within & 15u);
+#if MIRT_TILE_MORTON
+        // inside the tile along a Z curve: any 64 consecutive rays (one refill of a wave) cover an 8 x 8 block
+        auto even_bits = [](uint32_t v) {
+            v &= 0x55u;
+            v = (v | (v >> 1)) & 0x33u;
+            v = (v | (v >> 2)) & 0x0Fu;
+            return v;
+        };
+        const uint32_t wx = even_bits(within), wy = even_bits(within >> 1);
+#else
+        const uint32_t wx = within & 15u, wy = within >> 4;
+#endif
+        pixel = ((tile / tiles_x) * 16u + wy) * (uint32_t)cam.width + (tile % tiles_x) * 16u + wx;
     }
     uint32_t key = stream_key(seed, pixel, sample), ctr = 0;
     float u = rng_float(key, ctr);
