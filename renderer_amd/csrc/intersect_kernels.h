@@ -13,8 +13,12 @@
 //
 // Execution shape:
 //   * persistent waves: the grid is sized to the chip, not to the batch; each wave draws rays from a
-//     global queue in chunks of RAY_CHUNK (one atomic per chunk) and a lane whose ray is finished
-//     takes the next ray instead of idling until the slowest ray of its wave is done;
+//     global queue in chunks (64 / 128 / 256 rays by launch size and mode, one atomic per chunk) and a
+//     lane whose ray is finished takes the next ray of the chunk instead of idling until the slowest ray
+//     of its wave is done;
+//   * register budget by instantiation: the fast-tree kernels are built for 7 waves per SIMD (latency of
+//     the node loads is what they wait for), the exact ones for 5; the per-lane stack is addressed through
+//     pointers with explicit address spaces (LDS levels first, a global spill area behind them);
 //   * "while-while" traversal: all lanes descend inner nodes until each has reached a leaf (or run
 //     out of nodes), then all lanes test triangles of their leaf together;
 //   * one 64-byte PairRec load per inner step brings both children's boxes and links (breadth-first
