@@ -275,19 +275,20 @@ __device__ __forceinline__ int slab_classify(const float4 lo, const float4 hi, b
 // roundings, two at a time
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct RayPre2 {
-    v2f oxy, ozz, ixy, izz;  // origin / reciprocal direction as register pairs (broadcast by op_sel)
+    v2f oxy, ixy, ozi;  // origin / reciprocal direction as register pairs (halves broadcast by op_sel); ozi = (o.z, 1/d.z)
 };
 __device__ __forceinline__ RayPre2 ray_pairs(f3 o, const RayPre& p) {
     RayPre2 q;
-    q.oxy = v2f{o.x, o.y}, q.ozz = v2f{o.z, o.z};
-    q.ixy = v2f{p.inv.x, p.inv.y}, q.izz = v2f{p.inv.z, p.inv.z};
+    q.oxy = v2f{o.x, o.y};
+    q.ixy = v2f{p.inv.x, p.inv.y};
+    q.ozi = v2f{o.z, p.inv.z};
     return q;
 }
 __device__ __forceinline__ int slab_classify_pair(const float4 a, const float4 b, const RayPre2& q,
                                                   const RayPre& p, float& lb) {
     const v2f tx = (v2f{a.x, a.y} - q.oxy.xx) * q.ixy.xx;
     const v2f ty = (v2f{a.z, a.w} - q.oxy.yy) * q.ixy.yy;
-    const v2f tz = (v2f{b.x, b.y} - q.ozz.xx) * q.izz.xx;
+    const v2f tz = (v2f{b.x, b.y} - q.ozi.xx) * q.ozi.yy;
     const float nx = fminf(tx.x, tx.y), fx = fmaxf(tx.x, tx.y);
     const float ny = fminf(ty.x, ty.y), fy = fmaxf(ty.x, ty.y);
     const float nz = fminf(tz.x, tz.y), fz = fmaxf(tz.x, tz.y);
