@@ -460,7 +460,13 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
             redo = true;
         } else if (slot >= 0) {
             int node = sc.slot_node[slot];
-            while (node >= 0) {
+            // (the step bound can never bind: the host rejects trees deeper than MIRT_MAX_TREE_DEPTH and builds the
+            // parent links itself; it is there so that no state of the data can keep a wave in this loop)
+            for (int step = 0; node >= 0; step++) {
+                if (step > MIRT_MAX_TREE_DEPTH + 1) {
+                    redo = true;
+                    break;
+                }
                 const NodeRec N = sc.rnodes[node];
                 float lb;
                 const int code = slab_classify(N.lo, N.hi, __float_as_int(N.hi.w) != 0, o, pre, lb);
