@@ -80,8 +80,7 @@ def main():
         cam = scene.camera()
         scene_name = "BallsInFog"
     else:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import meshgen  # procedural mesh generator (not the oracle)
+        from renderer_amd import meshgen  # procedural mesh generator
         scene = meshgen.mesh_scene(7)
         cam = ra.make_camera(1024, 1024, 700)
         scene_name = "DisplacedIcospheres(level 7 x3: diffuse / glossy 5 / glass 1.5)"

@@ -192,6 +192,11 @@ const char* mirt_last_error(const MirtContext* ctx);
 /* --- scene --------------------------------------------------------------------------------
  * replaces IntersectionGPU::loadKDTreeToShader (IntersectionGPU.cpp:243-255).                */
 int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* scene);
+/* Number of successful mirt_upload_scene calls on this context so far (0: no scene). The reference keeps its
+ * tree textures in static state that whoever called loadKDTreeToShader last has overwritten
+ * (IntersectionGPU.cpp:5-14, 243-255); a caller that shares a context uses this to notice that the scene it
+ * uploaded is no longer the resident one (IntersectionHIP::isResident in renderer_amd/host/scene.cpp).   */
+uint64_t mirt_scene_serial(const MirtContext* ctx);
 
 /* --- batched closest hit ------------------------------------------------------------------
  * replaces IntersectionGPU::query (IntersectionGPU.cpp:216-241) as called from

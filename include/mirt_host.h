@@ -81,6 +81,10 @@ int mirth_test_path_list_visibility(MirthScene* s, int32_t n_paths, const int32_
 void mirth_world_vertex(const float m[16], const float v[3], float out[3]);
 void mirth_normal_transform(const float m[16], const float vn[3], float out[3]);
 void mirth_shutdown(void);
+/* 1 when this scene is the one the shared device service holds (IntersectionHIP::isResident: same Scene, same
+ * build of its tree and textures, nobody uploaded through the context since), else 0. Queries made through a
+ * scene check this themselves and upload again when needed; exported for tests and tools.            */
+int mirth_is_resident(const MirthScene* s);
 
 int mirth_save_pfm(const char* path, const float* rgb, int32_t w, int32_t h);
 int mirth_load_pfm(const char* path, float* rgb, int32_t capacity_pixels, int32_t wh[2]);

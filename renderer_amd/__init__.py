@@ -85,13 +85,13 @@ def texture_structs(textures):
 
 
 # every symbol include/mirt.h and include/mirt_host.h declare (checked by the CPU tests)
-MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_scene", "mirt_intersect",
+MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_scene", "mirt_scene_serial", "mirt_intersect",
                 "mirt_intersect_dev", "mirt_visibility", "mirt_visibility_dev", "mirt_fast_tree", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
                 "mirt_render_pt_dev", "mirt_render_pttest", "mirt_render_pttest_dev", "mirt_capture_rays_dev", "mirt_device_info"]
 MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_set_textures", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
                  "mirth_describe", "mirth_upload", "mirth_render", "mirth_render_progressive", "mirth_fill_intersect", "mirth_test_visibility", "mirth_test_path_list_visibility", "mirth_world_vertex", "mirth_normal_transform",
-                 "mirth_shutdown",
+                 "mirth_shutdown", "mirth_is_resident",
                  "mirth_save_pfm", "mirth_load_pfm"]
 
 _lib = None
@@ -116,7 +116,7 @@ def lib():
         L.mirth_last_error.restype = C.c_char_p
         for name in MIRT_SYMBOLS + MIRTH_SYMBOLS:
             fn = getattr(L, name)
-            if name not in ("mirt_last_error", "mirth_last_error", "mirth_free", "mirth_shutdown"):
+            if name not in ("mirt_last_error", "mirth_last_error", "mirth_free", "mirth_shutdown", "mirt_scene_serial"):
                 fn.restype = C.c_int
         L.mirth_free.restype = None
         L.mirth_free.argtypes = [C.c_void_p]
@@ -124,6 +124,8 @@ def lib():
         L.mirt_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.mirt_destroy.argtypes = [C.c_void_p]
         L.mirt_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        L.mirt_scene_serial.argtypes = [C.c_void_p]
+        L.mirt_scene_serial.restype = C.c_uint64
         L.mirt_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                      C.c_void_p, C.c_void_p]
         L.mirt_intersect_dev.argtypes = L.mirt_intersect.argtypes + [C.c_void_p]
@@ -165,6 +167,7 @@ def lib():
         L.mirth_world_vertex.restype = None
         L.mirth_normal_transform.argtypes = [C.c_void_p] * 3
         L.mirth_normal_transform.restype = None
+        L.mirth_is_resident.argtypes = [C.c_void_p]
         L.mirth_save_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         L.mirth_load_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32 * 2)]
         _lib = L
@@ -291,7 +294,9 @@ class HostScene:
         return d
 
     def upload(self):
-        """Scene::buildKDTree's device step; returns a Device bound to the service's context."""
+        """Scene::buildKDTree's device step; returns a Device bound to the service's ONE shared context (not owned):
+        a later upload of another scene re-points it. Queries made through a HostScene (fill_intersect,
+        test_visibility, render) notice that and upload their own scene again first."""
         ctx = C.c_void_p()
         if lib().mirth_upload(self.h, C.byref(ctx)) != 0:
             raise MirtError(lib().mirth_last_error().decode())

@@ -107,7 +107,8 @@ __device__ __forceinline__ bool candidate_legal(const DevScene& sc, const TriRec
 // passes (k_verify); no occluder in the superset means none in the reference's set. The kernel leaves the
 // occluder's slot in id_out for k_verify; rejected rays are answered by the exact any-hit kernel.
 // ray_list != nullptr: the queue hands out positions of ray_list, which holds the ray indices (the
-// exact re-run of the rays k_verify rejected).
+// exact re-run of the rays k_verify rejected); the launch does nothing unless the list holds more than
+// list_min rays (shorter lists are k_rerun's).
 #ifndef MIRT_BLOCK
 #define MIRT_BLOCK 256  // lanes per block of the traversal kernels (swept: 128 / 256 / 512)
 #endif
@@ -127,13 +128,15 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             int* __restrict__ id_out, unsigned long long* __restrict__ counters,
             uint32_t* __restrict__ queue, uint32_t lds_levels, uint2* __restrict__ spill,
             const float* __restrict__ limit = nullptr, unsigned char* __restrict__ vis_out = nullptr,
-            const uint32_t* __restrict__ ray_list = nullptr) {
+            const uint32_t* __restrict__ ray_list = nullptr, uint32_t list_min = 0) {
     extern __shared__ uint32_t lds[];
     constexpr int LEAF_BATCH = FAST ? LEAF_BATCH_FAST : LEAF_BATCH_EXACT;
     const PairRec* __restrict__ pairs = FAST ? sc.fpairs : sc.pairs;
     const float4 root_lo = FAST ? sc.froot_lo : sc.root_lo, root_hi = FAST ? sc.froot_hi : sc.root_hi;
     // ray count: given, or (wavefront path tracer) left in device memory by the previous shade pass
     const uint32_t n = n_ptr ? min(*n_ptr, n_direct) : n_direct;
+    // re-run of a LONG list only (launch_intersect): lists of at most list_min rays belong to k_rerun
+    if (ray_list != nullptr && n <= list_min) return;
     const uint32_t bs = blockDim.x;
     const uint32_t RAY_CHUNK = n < MIRT_RAY_CHUNK_MIN_RAYS ? RAY_CHUNK_SMALL
                                : (MODE == MIRT_MODE_NO_SELF ? MIRT_RAY_CHUNK_INCOHERENT : MIRT_RAY_CHUNK_COHERENT);
@@ -510,15 +513,22 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
 // Stack bound: batch steps (pop k <= 32, push <= 2k) only while sp <= CAP - 192, single-pair depth-first
 // steps above that, which add at most depth + 1 (<= MIRT_MAX_TREE_DEPTH + 1) entries.
 constexpr int RERUN_STACK = 2048;
+// Longest list k_rerun takes. Measured on the Cornell batch: 157 rays take 39 us wave-wide and 424 us with one lane per
+// ray (the slowest ray's ~200 dependent exact box tests); the wave-wide time grows with count / 1024 waves, the other
+// barely, and they cross near 10^4 rays.
+constexpr uint32_t RERUN_WIDE_MAX = 8192;
 template <bool SLOT_OUT, int MODE = MIRT_MODE_NO_SELF>
 __global__ void __launch_bounds__(64)
 k_rerun(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, const int* __restrict__ aux,
         uint32_t plane_stride, float* __restrict__ t_out, int* __restrict__ id_out,
-        const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
+        const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count, uint32_t list_max) {
     __shared__ int stack[RERUN_STACK];
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t count = *list_count;
+    // one wave per ray pays for short lists only; a long one (a batch of axis-parallel rays, which the classifier's
+    // model excludes wholesale) goes to the lane-per-ray exact kernel launched next (launch_intersect)
+    if (count > list_max) return;
     for (uint32_t r = blockIdx.x; r < count; r += gridDim.x) {
         const uint32_t idx = list[r];
         const f3 o = mk3(O[idx], O[plane_stride + idx], O[2 * plane_stride + idx]);

@@ -33,6 +33,7 @@ struct MirtContext {
     DevObject* d_objs = nullptr;
     DevScene sc{};
     bool has_scene = false;
+    uint64_t scene_serial = 0; // successful uploads so far (mirt_scene_serial)
     bool has_media = false;    // scene holds a homogeneous medium (MIRT_OBJ_VPM)
     bool media_ready = true;   // ... and every such object came with its own tree
     VolRoot* d_vols = nullptr;
@@ -53,13 +54,13 @@ struct MirtContext {
     bool fast_all_modes = false;    // modes 0 / 1 through the fast tree too (large scenes)
     // modes 0 / 1 on smaller scenes: which path is faster depends on the rays (camera inside or outside the
     // geometry ...), so the first large call of a mode runs BOTH paths, times them and keeps the faster one for the
-    // scene (one extra launch and one stream synchronisation, once per scene and mode; both paths return the same
-    // answers). state: 0 untimed, 3 decided.
+    // scene (three extra launches of each and one stream synchronisation, once per scene and mode; both paths return
+    // the same answers; tune_routes). state: 0 untimed, 3 decided.
     struct PathTune {
         int state = 0;
         bool use_fast = false;
         double exact_ns_per_ray = 0, fast_ns_per_ray = 0;
-        hipEvent_t a = nullptr, b = nullptr, c = nullptr;
+        hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     } tune[2];
     bool tune_modes = true;
     float* d_light_area = nullptr;
@@ -99,6 +100,7 @@ struct MirtContext {
 };
 
 static thread_local std::string g_create_err;
+
 
 #define HIPCHK(ctx, call)                                                                       \
     do {                                                                                        \
@@ -263,12 +265,11 @@ int mirt_destroy(MirtContext* ctx) {
     hipFree(ctx->d_wq2);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_queue);
-    for (auto& t : ctx->tune) {
-        if (t.a) hipEventDestroy(t.a);
-        if (t.b) hipEventDestroy(t.b);
-        if (t.c) hipEventDestroy(t.c);
-        t.a = t.b = t.c = nullptr;
-    }
+    for (auto& t : ctx->tune)
+        for (hipEvent_t& e : t.ev) {
+            if (e) hipEventDestroy(e);
+            e = nullptr;
+        }
     hipFree(ctx->d_fb_list);
     hipFree(ctx->d_vis_slot);
     if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
@@ -276,6 +277,8 @@ int mirt_destroy(MirtContext* ctx) {
     delete ctx;
     return MIRT_OK;
 }
+
+uint64_t mirt_scene_serial(const MirtContext* ctx) { return ctx && ctx->has_scene ? ctx->scene_serial : 0; }
 
 int mirt_device_info(MirtContext* ctx, char* buf, size_t buflen) {
     if (!ctx || !buf || buflen == 0) return MIRT_E_INVALID;
@@ -911,7 +914,9 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     ctx->sc.froot_hi = froot_hi;
     ctx->sc.rnodes = ctx->d_rnodes;
     ctx->sc.slot_node = ctx->d_slot_node;
-    ctx->fast_tree = use_fast;
+    // (a scene outside the classifier's model, fast_ok = 0, would have every ray skipped by the fast walk, listed
+    // by k_verify and re-run exactly: it stays on the reference tree alone)
+    ctx->fast_tree = use_fast && fast_ok;
     // Modes 0 / 1 (coherent camera rays, as a rule): on the Cornell scene the reference tree alone is faster
     // (0.89 vs 0.98 ms per 4 Mi rays: verify + re-run cost more than the shorter walk saves), on the 1 M-triangle
     // scene the fast tree is (1.99 -> 1.57 ms): the walk is what waits for memory there.
@@ -1021,6 +1026,7 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     if (std::max(spill_a, spill_b))
         HIPCHK(ctx, hipMalloc(&ctx->d_spill, std::max(spill_a, spill_b) * ctx->block * sizeof(uint2)));
     ctx->has_scene = true;
+    ctx->scene_serial++;
     ctx->has_media = n_vpm > 0;
     ctx->media_ready = media_ready;
     return MIRT_OK;
@@ -1029,44 +1035,53 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
 }  // extern "C"
 
 // ---- launches -------------------------------------------------------------------------------------
+// Scratch buffers of one closest-hit call: the context's own (hipMalloc'd, grown on demand) or, for
+// mirt_intersect_noalloc_dev, slices of the static device array.
+struct LaunchBufs {
+    uint32_t* list;            // ray indices k_verify hands to the exact re-run (one per ray of the batch)
+    uint2* spill;              // stack levels beyond the LDS share
+    uint32_t max_blocks;       // grid caps the spill area is sized for: exact kernels / fast-tree kernels
+    uint32_t max_blocks_fast;
+};
+
 template <int MODE, bool COUNT, bool SLOT_OUT, bool FAST>
-static void launch_pair(MirtContext* ctx, hipStream_t st, dim3 grid, dim3 block, const float* O, const float* D,
+static void launch_pair(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, dim3 grid, dim3 block, const float* O, const float* D,
                         const int* aux, uint32_t n, const uint32_t* n_ptr, uint32_t stride, float* t_out,
-                        int* id_out, uint32_t* queue, const uint32_t* ray_list) {
+                        int* id_out, uint32_t* queue, const uint32_t* ray_list, uint32_t list_min = 0) {
     if constexpr (MODE == MIRT_MODE_NO_SELF && !COUNT && !FAST) {
         if (ctx->has_bump) {  // the predicate reads the bumped normal (SceneObject.cpp:250-283)
             hipLaunchKernelGGL((k_intersect<MODE, false, SLOT_OUT, false, false, true>), grid, block, ctx->lds_main, st,
                                ctx->sc, O, D, aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue,
-                               ctx->lds_levels, ctx->d_spill, (const float*)nullptr, (unsigned char*)nullptr, ray_list);
+                               ctx->lds_levels, lb.spill, (const float*)nullptr, (unsigned char*)nullptr, ray_list, list_min);
             return;
         }
     }
     if constexpr (FAST) {  // built for more waves per SIMD: its own grid and LDS share
-        const dim3 g(std::min<uint32_t>((n + block.x - 1) / block.x, (uint32_t)ctx->max_blocks_fast));
+        const dim3 g(std::min<uint32_t>((n + block.x - 1) / block.x, lb.max_blocks_fast));
         hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT, false, true>), g, block, ctx->lds_main_fast, st, ctx->sc, O,
                            D, aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue, ctx->lds_levels_fast,
-                           ctx->d_spill, (const float*)nullptr, (unsigned char*)nullptr, ray_list);
+                           lb.spill, (const float*)nullptr, (unsigned char*)nullptr, ray_list, list_min);
         return;
     }
     hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT, false, FAST>), grid, block, ctx->lds_main, st, ctx->sc, O, D,
-                       aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue, ctx->lds_levels, ctx->d_spill,
-                       (const float*)nullptr, (unsigned char*)nullptr, ray_list);
+                       aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue, ctx->lds_levels, lb.spill,
+                       (const float*)nullptr, (unsigned char*)nullptr, ray_list, list_min);
 }
 
 template <bool COUNT, bool SLOT_OUT, bool FAST>
-static int launch_mode(MirtContext* ctx, hipStream_t st, dim3 grid, dim3 block, int mode, const float* O,
+static int launch_mode(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, dim3 grid, dim3 block, int mode, const float* O,
                        const float* D, const int* aux, uint32_t n, const uint32_t* n_ptr, uint32_t stride,
-                       float* t_out, int* id_out, uint32_t* queue, const uint32_t* ray_list) {
+                       float* t_out, int* id_out, uint32_t* queue, const uint32_t* ray_list, uint32_t list_min = 0) {
     switch (mode) {
         case MIRT_MODE_UNCONDITIONAL:
-            launch_pair<MIRT_MODE_UNCONDITIONAL, COUNT, SLOT_OUT, FAST>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue, ray_list);
+            launch_pair<MIRT_MODE_UNCONDITIONAL, COUNT, SLOT_OUT, FAST>(ctx, lb, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue, ray_list, list_min);
             break;
         case MIRT_MODE_LAST_TID:
-            launch_pair<MIRT_MODE_LAST_TID, COUNT, SLOT_OUT, FAST>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue, ray_list);
+            launch_pair<MIRT_MODE_LAST_TID, COUNT, SLOT_OUT, FAST>(ctx, lb, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue, ray_list, list_min);
             break;
         case MIRT_MODE_NO_SELF:
             if (COUNT && ctx->has_bump) return fail(ctx, MIRT_E_INVALID, "intersect: scenes with bump textures cannot be instrumented");
-            launch_pair<MIRT_MODE_NO_SELF, COUNT, SLOT_OUT, FAST>(ctx, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue, ray_list);
+            launch_pair<MIRT_MODE_NO_SELF, COUNT, SLOT_OUT, FAST>(ctx, lb, st, grid, block, O, D, aux, n, n_ptr, stride, t_out, id_out, queue, ray_list, list_min);
             break;
         default:
             return fail(ctx, MIRT_E_INVALID, "intersect: unknown mode");
@@ -1088,77 +1103,63 @@ static int ensure_fb_list(MirtContext* ctx, hipStream_t st, uint32_t n) {
     return MIRT_OK;
 }
 
-// Closest hit of n rays (n_ptr != nullptr: the count is read on the device, at most n). With the fast
-// tree: three launches, k_intersect<FAST> over the fast tree, k_verify (the winner's chain of reference
-// boxes, by the reference's test), and the exact kernel over the reference tree for the rays k_verify
-// listed (few: ~1e-5 of a batch, plus rays with zero / extreme components). `qwords`: three zeroed words
-// owned by this call (queue head of the fast launch, list length, queue head of the exact launch).
-// exact_only: the reference tree alone (the audit entry point, and scenes without a fast tree).
+// The context's own scratch buffers (the list grows to the largest batch so far: may allocate and synchronise).
+static int context_bufs(MirtContext* ctx, hipStream_t st, uint32_t n, bool need_list, LaunchBufs* lb) {
+    if (need_list && ensure_fb_list(ctx, st, n) != MIRT_OK) return MIRT_E_HIP;
+    lb->list = ctx->d_fb_list;
+    lb->spill = ctx->d_spill;
+    lb->max_blocks = (uint32_t)ctx->max_blocks;
+    lb->max_blocks_fast = (uint32_t)ctx->max_blocks_fast;
+    return MIRT_OK;
+}
+
+// The reference tree alone: one launch of the exact kernel.
 template <bool COUNT, bool SLOT_OUT>
-static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
-                            const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out,
-                            const uint32_t* n_ptr = nullptr, uint32_t* qwords = nullptr, bool exact_only = false) {
-    if (n == 0) return MIRT_OK;
+static int route_exact(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, int mode, const float* O, const float* D,
+                       const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out, const uint32_t* n_ptr,
+                       uint32_t* qwords) {
     const uint32_t want = (n + ctx->block - 1) / ctx->block;
-    dim3 block(ctx->block), grid(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks));
-    if (!qwords) {
-        qwords = ctx->d_queue;
-        HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
-    }
-    // the fast path serves the predicate mode (incoherent rays), on large scenes the other two as well
-    // (ctx->fast_all_modes, set at upload), and on the rest whichever path the first large calls showed faster
-    bool use_fast = !exact_only && ctx->fast_tree && (mode == MIRT_MODE_NO_SELF || ctx->fast_all_modes);
-    MirtContext::PathTune* timed = nullptr;
-    if (!exact_only && ctx->fast_tree && !ctx->fast_all_modes && ctx->tune_modes &&
-        (mode == MIRT_MODE_UNCONDITIONAL || mode == MIRT_MODE_LAST_TID)) {
-        MirtContext::PathTune& T = ctx->tune[mode];
-        if (T.state == 3) {
-            use_fast = T.use_fast;  // (the instrumented calls follow the choice, they never make it)
-        } else if (!COUNT && !n_ptr && n >= (1u << 18)) {
-            if (!T.a && (hipEventCreate(&T.a) != hipSuccess || hipEventCreate(&T.b) != hipSuccess ||
-                         hipEventCreate(&T.c) != hipSuccess)) {
-                T.state = 3;  // no events: stay on the reference tree
-            } else {  // the reference tree first (timed here), then fall through to the fast path (timed below)
-                HIPCHK(ctx, hipEventRecord(T.a, st));
-                const int rc0 = launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride,
-                                                                    t_out, id_out, qwords, nullptr);
-                if (rc0 != MIRT_OK) return rc0;
-                HIPCHK(ctx, hipEventRecord(T.b, st));
-                HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
-                use_fast = true;
-                timed = &T;
-            }
-        }
-    }
-    if (!use_fast) {
-        const int rc0 = launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out,
-                                                            id_out, qwords, nullptr);
-        return rc0;
-    }
-    if (ensure_fb_list(ctx, st, n) != MIRT_OK) return MIRT_E_HIP;
-    int rc = launch_mode<COUNT, SLOT_OUT, true>(ctx, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out, id_out,
+    const dim3 block(ctx->block), grid(std::min<uint32_t>(want, lb.max_blocks));
+    return launch_mode<COUNT, SLOT_OUT, false>(ctx, lb, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out, id_out,
+                                               qwords, nullptr);
+}
+
+// The fast route: k_intersect<FAST> over the fast tree, k_verify (the winner's chain of reference boxes, by
+// the reference's test), and the exact re-run on the reference tree of the rays k_verify listed (few: ~1e-5 of a
+// batch, plus rays with zero / extreme components).
+template <bool COUNT, bool SLOT_OUT>
+static int route_fast(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, int mode, const float* O, const float* D,
+                      const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out, const uint32_t* n_ptr,
+                      uint32_t* qwords) {
+    const uint32_t want = (n + ctx->block - 1) / ctx->block;
+    const dim3 block(ctx->block), grid(std::min<uint32_t>(want, lb.max_blocks));
+    int rc = launch_mode<COUNT, SLOT_OUT, true>(ctx, lb, st, grid, block, mode, O, D, aux, n, n_ptr, stride, t_out, id_out,
                                                 qwords, nullptr);
     if (rc != MIRT_OK) return rc;
     hipLaunchKernelGGL((k_verify<SLOT_OUT, COUNT>), dim3((n + 255) / 256), dim3(256), 0, st, ctx->sc, O, D, n, n_ptr, stride,
-                       (const float*)t_out, id_out, ctx->d_fb_list, qwords + 1, ctx->d_counters);
+                       (const float*)t_out, id_out, lb.list, qwords + 1, ctx->d_counters);
     HIPCHK(ctx, hipGetLastError());
     // the listed rays, by the reference arithmetic on the reference tree: one wave per ray (k_rerun); the
     // instrumented call keeps the one-lane-per-ray kernel, whose counters the audit reads
     static const bool rerun_wide = !getenv("MIRT_RERUN_WIDE") || atoi(getenv("MIRT_RERUN_WIDE")) != 0;  // A/B switch
     if (!COUNT && rerun_wide) {
         const dim3 rg(std::min<uint32_t>(n, 1024)), rb(64);
-        const uint32_t* list = ctx->d_fb_list;
+        const uint32_t* list = lb.list;
         const uint32_t* count = qwords + 1;
         if (mode == MIRT_MODE_NO_SELF)
-            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_NO_SELF>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count);
+            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_NO_SELF>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count, RERUN_WIDE_MAX);
         else if (mode == MIRT_MODE_LAST_TID)
-            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_LAST_TID>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count);
+            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_LAST_TID>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count, RERUN_WIDE_MAX);
         else
-            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_UNCONDITIONAL>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count);
+            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_UNCONDITIONAL>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count, RERUN_WIDE_MAX);
         HIPCHK(ctx, hipGetLastError());
+        // a list longer than that (whole batches outside the classifier's model: axis-parallel rays) is re-run with one
+        // lane per ray by the persistent exact kernel; each of the two launches returns at once when the list is the other's
+        rc = launch_mode<false, SLOT_OUT, false>(ctx, lb, st, grid, block, mode, O, D, aux, n, qwords + 1, stride, t_out, id_out,
+                                                 qwords + 2, lb.list, RERUN_WIDE_MAX);
     } else {
-        rc = launch_mode<COUNT, SLOT_OUT, false>(ctx, st, grid, block, mode, O, D, aux, n, qwords + 1, stride, t_out,
-                                                 id_out, qwords + 2, ctx->d_fb_list);
+        rc = launch_mode<COUNT, SLOT_OUT, false>(ctx, lb, st, grid, block, mode, O, D, aux, n, qwords + 1, stride, t_out,
+                                                 id_out, qwords + 2, lb.list);
     }
     static const bool debug_list = getenv("MIRT_DEBUG_LIST") != nullptr;
     if (debug_list && rc == MIRT_OK) {  // diagnostics only: synchronises the stream
@@ -1167,22 +1168,93 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
         hipMemcpy(h, qwords, sizeof(h), hipMemcpyDeviceToHost);
         fprintf(stderr, "[mirt] fast path: %u rays, %u re-run on the reference tree\n", n, h[1]);
     }
-    if (timed && rc == MIRT_OK) {
-        HIPCHK(ctx, hipEventRecord(timed->c, st));
-        HIPCHK(ctx, hipEventSynchronize(timed->c));
-        float ms_exact = 0.f, ms_fast = 0.f;
-        if (hipEventElapsedTime(&ms_exact, timed->a, timed->b) == hipSuccess &&
-            hipEventElapsedTime(&ms_fast, timed->b, timed->c) == hipSuccess) {
-            timed->exact_ns_per_ray = (double)ms_exact * 1e6 / n;
-            timed->fast_ns_per_ray = (double)ms_fast * 1e6 / n;
-            timed->use_fast = ms_fast < 0.97f * ms_exact;
-            if (getenv("MIRT_DEBUG_TUNE"))
-                fprintf(stderr, "[mirt] mode %d: reference tree %.3f ns/ray, fast tree %.3f ns/ray -> %s\n", mode,
-                        timed->exact_ns_per_ray, timed->fast_ns_per_ray, timed->use_fast ? "fast tree" : "reference tree");
-        }
-        timed->state = 3;
-    }
     return rc;
+}
+
+// Modes 0 / 1 on scenes below fast_all_modes' size: which route is faster depends on the rays, so the first call of
+// a mode with >= 2^18 rays on a scene runs BOTH routes three times each, alternating, times them with events and keeps
+// the one with the smaller median for that scene and mode (both return the same answers; the caller's buffers hold
+// the last run's). Synchronises the stream and creates events: never reached from mirt_intersect_noalloc_dev.
+template <bool SLOT_OUT>
+static int tune_routes(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, int mode, const float* O, const float* D,
+                       const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out, uint32_t* qwords) {
+    MirtContext::PathTune& T = ctx->tune[mode];
+    constexpr int REPS = 3;
+    for (hipEvent_t& e : T.ev)
+        if (!e && hipEventCreate(&e) != hipSuccess) {
+            T.state = 3;  // no events: stay on the reference tree
+            T.use_fast = false;
+            return route_exact<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, n, stride, t_out, id_out, nullptr, qwords);
+        }
+    HIPCHK(ctx, hipEventRecord(T.ev[0], st));
+    for (int r = 0; r < REPS; r++) {
+        HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
+        int rc = route_exact<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, n, stride, t_out, id_out, nullptr, qwords);
+        if (rc != MIRT_OK) return rc;
+        HIPCHK(ctx, hipEventRecord(T.ev[2 * r + 1], st));
+        HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
+        rc = route_fast<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, n, stride, t_out, id_out, nullptr, qwords);
+        if (rc != MIRT_OK) return rc;
+        HIPCHK(ctx, hipEventRecord(T.ev[2 * r + 2], st));
+    }
+    HIPCHK(ctx, hipEventSynchronize(T.ev[2 * REPS]));
+    float ex[REPS], fa[REPS];
+    bool ok = true;
+    for (int r = 0; r < REPS; r++)
+        ok = ok && hipEventElapsedTime(&ex[r], T.ev[2 * r], T.ev[2 * r + 1]) == hipSuccess &&
+             hipEventElapsedTime(&fa[r], T.ev[2 * r + 1], T.ev[2 * r + 2]) == hipSuccess;
+    if (ok) {
+        std::sort(ex, ex + REPS);
+        std::sort(fa, fa + REPS);
+        T.exact_ns_per_ray = (double)ex[REPS / 2] * 1e6 / n;
+        T.fast_ns_per_ray = (double)fa[REPS / 2] * 1e6 / n;
+        T.use_fast = fa[REPS / 2] < 0.97f * ex[REPS / 2];
+        if (getenv("MIRT_DEBUG_TUNE"))
+            fprintf(stderr, "[mirt] mode %d: reference tree %.3f ns/ray, fast tree %.3f ns/ray (medians of %d) -> %s\n", mode,
+                    T.exact_ns_per_ray, T.fast_ns_per_ray, REPS, T.use_fast ? "fast tree" : "reference tree");
+    }
+    T.state = 3;
+    return MIRT_OK;
+}
+
+// Closest hit of n rays (n_ptr != nullptr: the count is read on the device, at most n). `qwords`: three zeroed
+// words owned by this call (queue head of the fast launch, list length, queue head of the exact launch).
+// exact_only: the reference tree alone (the audit entry point, and scenes without a fast tree).
+// bufs: the scratch buffers to use instead of the context's own; with them the call allocates nothing, creates no
+// events and never synchronises (mirt_intersect_noalloc_dev).
+template <bool COUNT, bool SLOT_OUT>
+static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
+                            const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out,
+                            const uint32_t* n_ptr = nullptr, uint32_t* qwords = nullptr, bool exact_only = false,
+                            const LaunchBufs* bufs = nullptr) {
+    if (n == 0) return MIRT_OK;
+    // the fast route serves the predicate mode (incoherent rays), on large scenes the other two as well
+    // (ctx->fast_all_modes, set at upload), and on the rest whichever route the first large call showed faster
+    bool use_fast = !exact_only && ctx->fast_tree && (mode == MIRT_MODE_NO_SELF || ctx->fast_all_modes);
+    bool tune = false;
+    if (!exact_only && ctx->fast_tree && !ctx->fast_all_modes && ctx->tune_modes &&
+        (mode == MIRT_MODE_UNCONDITIONAL || mode == MIRT_MODE_LAST_TID)) {
+        MirtContext::PathTune& T = ctx->tune[mode];
+        if (T.state == 3)
+            use_fast = T.use_fast;  // (the instrumented calls follow the choice, they never make it)
+        else
+            tune = !COUNT && !n_ptr && !bufs && n >= (1u << 18);
+    }
+    LaunchBufs own;
+    if (!bufs) {
+        const int rc = context_bufs(ctx, st, n, use_fast || tune, &own);
+        if (rc != MIRT_OK) return rc;
+        bufs = &own;
+    }
+    if (!qwords) {
+        qwords = ctx->d_queue;
+        HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
+    }
+    if constexpr (!COUNT) {
+        if (tune) return tune_routes<SLOT_OUT>(ctx, *bufs, st, mode, O, D, aux, n, stride, t_out, id_out, qwords);
+    }
+    if (!use_fast) return route_exact<COUNT, SLOT_OUT>(ctx, *bufs, st, mode, O, D, aux, n, stride, t_out, id_out, n_ptr, qwords);
+    return route_fast<COUNT, SLOT_OUT>(ctx, *bufs, st, mode, O, D, aux, n, stride, t_out, id_out, n_ptr, qwords);
 }
 
 // visibility variant: vis_out[i] = 1 unless a legal hit lies nearer than limit[i]. `queue`: THREE zeroed words

@@ -393,8 +393,9 @@ void MCRenderer::showCurrentResult(const std::vector<vec3f>& pixelColors, int w,
 // Here the passes run on the device in slices; the sums come back per slice and are divided by the
 // number of passes they hold.
 std::vector<vec3f> PathTracerHIP::renderPixels(const Camera& camera) {
+    if (!renderer) throw std::runtime_error("PathTracerHIP::renderPixels: no Renderer");
+    IntersectionHIP::ensureResident(renderer->scene);  // (another scene may have been uploaded since this one was)
     MirtContext* ctx = IntersectionHIP::context();
-    if (!ctx) throw std::runtime_error("PathTracerHIP::renderPixels: the scene was not loaded to the device");
     const size_t npix = (size_t)camera.width * camera.height;
     if (!resume || sums.size() != 3 * npix) {
         sums.assign(3 * npix, 0.f);

@@ -175,6 +175,12 @@ public:
     static void shutdown();
     static MirtContext* context();
     static void loadKDTreeToDevice(const Scene& scene);
+    // The service holds ONE scene at a time (like the reference's static GL state, IntersectionGPU.cpp:5-14).
+    // loadKDTreeToDevice records which (the Scene and the generation of its tree); every query made through a
+    // Scene first calls ensureResident, which uploads that scene again when another one (or an older tree of
+    // the same one) is on the device, so a query can never be answered from somebody else's geometry.
+    static bool isResident(const Scene& scene);
+    static void ensureResident(const Scene& scene);
     // mode MIRT_MODE_LAST_TID with ray.last_tid, like IntersectionGPU::query
     static std::vector<Hit> query(const std::vector<Ray>& rays);
     // general form: aux per ray, any MIRT_MODE_*
@@ -189,6 +195,8 @@ public:
     std::vector<unsigned> objTriangleOffsetMap;
     std::vector<SceneObject*> objects;
     bool useGPU = true;  // the HIP path is the only one this library has
+    unsigned long long generation = 0;  // unique stamp of the current tree + textures (0: none built), see IntersectionHIP::isResident
+    void touch();                       // new stamp: whatever is on the device no longer describes this scene
     // flattened per-triangle data (by global triangle id), filled by buildKDTree
     std::vector<float> triPos;       // 9 per triangle
     std::vector<int32_t> triObj, triLocal;

@@ -101,6 +101,7 @@ int mirth_scene_from_arrays(int32_t n_verts, const float* verts, int32_t n_tris,
         }
         sc.tree.build();
         sc.buildObjKDTrees();
+        sc.touch();
     } catch (const std::exception& e) {
         g_err = e.what();
         delete s;
@@ -158,6 +159,7 @@ int mirth_set_textures(MirthScene* s, const float* tri_vt, int32_t n_textures, c
         sc.textureDescs.push_back(t->describe());
     }
     if (n_textures > 0) sc.objectTex.assign(object_tex, object_tex + sc.objectDescs.size());
+    sc.touch();  // a copy on the device was uploaded without these textures
     return 0;
 }
 
@@ -397,6 +399,8 @@ void mirth_normal_transform(const float m[16], const float vn[3], float out[3]) 
 }
 
 void mirth_shutdown(void) { IntersectionHIP::shutdown(); }
+
+int mirth_is_resident(const MirthScene* s) { return s && IntersectionHIP::isResident(s->renderer.scene) ? 1 : 0; }
 
 int mirth_save_pfm(const char* path, const float* rgb, int32_t w, int32_t h) {
     if (!path || !rgb || w <= 0 || h <= 0) return -1;

@@ -21,6 +21,10 @@ MirtCamera Camera::toMirt() const {
 
 // ---- IntersectionHIP: the static service IntersectionGPU was (IntersectionGPU.cpp:5-14) -----------
 static MirtContext* g_ctx = nullptr;
+static const Scene* g_resident = nullptr;        // the scene whose tree is on the device ...
+static unsigned long long g_resident_gen = 0;    // ... and which build of it
+static uint64_t g_resident_serial = 0;           // mirt_scene_serial right after that upload (someone else may upload through the context)
+static unsigned long long g_next_generation = 0; // stamps handed to Scene::buildKDTree
 
 void IntersectionHIP::init(int device) {
     if (g_ctx) return;
@@ -32,6 +36,8 @@ void IntersectionHIP::init(int device) {
 void IntersectionHIP::shutdown() {
     if (g_ctx) mirt_destroy(g_ctx);
     g_ctx = nullptr;
+    g_resident = nullptr;
+    g_resident_gen = 0;
 }
 
 MirtContext* IntersectionHIP::context() { return g_ctx; }
@@ -39,8 +45,26 @@ MirtContext* IntersectionHIP::context() { return g_ctx; }
 void IntersectionHIP::loadKDTreeToDevice(const Scene& scene) {
     if (!g_ctx) throw std::runtime_error("IntersectionHIP::loadKDTreeToDevice: init() was not called");
     MirtSceneDesc d = scene.describe();
-    if (mirt_upload_scene(g_ctx, &d) != MIRT_OK)
+    if (mirt_upload_scene(g_ctx, &d) != MIRT_OK) {
+        g_resident = nullptr;  // (a failed upload leaves no scene on the device)
+        g_resident_gen = 0;
         throw std::runtime_error(std::string("IntersectionHIP::loadKDTreeToDevice: ") + mirt_last_error(g_ctx));
+    }
+    g_resident = &scene;
+    g_resident_gen = scene.generation;
+    g_resident_serial = mirt_scene_serial(g_ctx);
+}
+
+bool IntersectionHIP::isResident(const Scene& scene) {
+    return g_ctx && g_resident == &scene && scene.generation != 0 && g_resident_gen == scene.generation &&
+           mirt_scene_serial(g_ctx) == g_resident_serial;
+}
+
+void IntersectionHIP::ensureResident(const Scene& scene) {
+    if (isResident(scene)) return;
+    if (!scene.tree.built()) throw std::runtime_error("IntersectionHIP: the scene has no tree (Scene::buildKDTree was not called)");
+    init();
+    loadKDTreeToDevice(scene);
 }
 
 std::vector<IntersectionHIP::Hit> IntersectionHIP::query(const std::vector<Ray>& rays, int mode) {
@@ -72,6 +96,8 @@ std::vector<IntersectionHIP::Hit> IntersectionHIP::query(const std::vector<Ray>&
 Scene::~Scene() { clear(); }
 
 void Scene::clear() {
+    generation = 0;
+    if (g_resident == this) g_resident = nullptr;  // (the device copy stays until the next upload; nothing may query it)
     for (SceneObject* o : objects) delete o;
     objects.clear();
     tree.destroy();
@@ -93,7 +119,10 @@ void Scene::clear() {
 // Scene::buildKDTree (Scene.cpp:248-285): concatenate every object's world-space vertices and
 // index-shifted triangles, remember (objID, triangleID) per global triangle, build the tree; then
 // hand the flattened tree to the device (the reference does the same for its GL path, :276-284).
+void Scene::touch() { generation = ++g_next_generation; }
+
 void Scene::buildKDTree(bool upload) {
+    touch();
     tree.destroy();
     objTriangleOffsetMap.clear();
     triPos.clear();
@@ -266,8 +295,12 @@ float Scene::intersect(const Ray& ray, ObjSourceInformation& objSource) {
     one[0].origin = ray.origin;
     one[0].direction = ray.direction;
     one[0].last_tid = -1;
+    IntersectionHIP::ensureResident(*this);
     IntersectionHIP::Hit h = IntersectionHIP::query(one, MIRT_MODE_UNCONDITIONAL)[0];
-    if (h.dist >= 0) objSource = tree.triangleList[h.tid].sourceInformation;
+    if (h.dist >= 0) {
+        if (h.tid < 0 || (size_t)h.tid >= tree.triangleList.size()) throw std::runtime_error("Scene::intersect: triangle id out of range");
+        objSource = tree.triangleList[h.tid].sourceInformation;
+    }
     return h.dist;
 }
 
@@ -290,9 +323,12 @@ void Scene::fillIntersectObject(std::vector<Ray>& rays) {
         int inside = rays[i].insideObject ? rays[i].insideObject->objectIndex : -1;
         q[i].last_tid = MIRT_PACK_IDS(contact, inside);
     }
+    IntersectionHIP::ensureResident(*this);
     std::vector<IntersectionHIP::Hit> hits = IntersectionHIP::query(q, MIRT_MODE_NO_SELF);
     for (size_t i = 0; i < rays.size(); i++) {
         if (hits[i].dist >= 0) {
+            if (hits[i].tid < 0 || (size_t)hits[i].tid >= tree.triangleList.size())
+                throw std::runtime_error("Scene::fillIntersectObject: triangle id out of range");
             const ObjSourceInformation& osi = tree.triangleList[hits[i].tid].sourceInformation;
             rays[i].intersectObject = objects[osi.objID];
             rays[i].intersectDist = hits[i].dist;
@@ -308,11 +344,11 @@ void Scene::fillIntersectObject(std::vector<Ray>& rays) {
 // (as fillIntersectObject does), i.e. the rule of the CPU route MCRenderer::testVisibility
 // (MCRenderer.cpp:115-117), as one any-hit batch: no second pass is needed.
 std::vector<bool> Scene::testVisibility(const std::vector<Ray>& rays) {
-    MirtContext* ctx = IntersectionHIP::context();
-    if (!ctx) throw std::runtime_error("Scene::testVisibility: IntersectionHIP::init() was not called");
     const size_t n = rays.size();
     std::vector<bool> visibilityList(n);
     if (n == 0) return visibilityList;
+    IntersectionHIP::ensureResident(*this);
+    MirtContext* ctx = IntersectionHIP::context();
     std::vector<float> o(3 * n), d(3 * n), lim(n);
     std::vector<int32_t> aux(n);
     std::vector<uint8_t> vis(n);

@@ -440,6 +440,38 @@ def test_host_surface_fill_intersect(cornell, cornell_oracle, ra):
     assert (obj[~hit] == -1).all()
 
 
+def test_two_scenes_interleaved_on_the_shared_service(cornell, cornell_oracle, ra, orc):
+    """IntersectionHIP holds ONE scene at a time (like the reference's static GL state). A query made through
+    scene A after scene B was uploaded must not be answered from B's geometry: every Scene query checks that it
+    is the resident scene and uploads itself again if not."""
+    other = ra.HostScene.load_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "Data",
+                                                  "Config_Cube128.xml"))
+    other_oracle = orc.OracleScene(other.raw())
+    o, d, _ = meshgen.random_rays(20000, 89, min(cornell.n_objects, other.n_objects))
+    contact = np.full(20000, -1, np.int32)
+    inside = np.full(20000, -1, np.int32)
+    ta, ia = cornell_oracle.intersect(o, d, ra.pack_ids(contact, inside), ra.MODE_NO_SELF, threads=16)
+    tb, ib = other_oracle.intersect(o, d, ra.pack_ids(contact, inside), ra.MODE_NO_SELF, threads=16)
+    assert not np.array_equal(ia, ib)
+    cornell.upload()
+    dev_b = other.upload()  # B is now the resident scene
+    assert ra.lib().mirth_is_resident(other.h) == 1 and ra.lib().mirth_is_resident(cornell.h) == 0
+    dist, tid, _, _ = cornell.fill_intersect(o.T.copy(), d.T.copy(), contact, inside)  # A again: re-uploads itself
+    assert np.array_equal(tid, ia) and np.array_equal(dist, ta)
+    assert ra.lib().mirth_is_resident(cornell.h) == 1 and ra.lib().mirth_is_resident(other.h) == 0
+    dist, tid, _, _ = other.fill_intersect(o.T.copy(), d.T.copy(), contact, inside)
+    assert np.array_equal(tid, ib) and np.array_equal(dist, tb)
+    vis = cornell.test_visibility(o.T.copy(), d.T.copy(), contact, inside, np.full(20000, 0.5, np.float32))
+    assert np.array_equal(vis, cornell_oracle.visibility(o, d, ra.pack_ids(contact, inside), np.full(20000, 0.5, np.float32)))
+    # an upload made behind the service's back (straight through the shared context) is noticed too
+    dev_b.upload(other.describe())
+    assert ra.lib().mirth_is_resident(cornell.h) == 0
+    dist, tid, _, _ = cornell.fill_intersect(o.T.copy(), d.T.copy(), contact, inside)
+    assert np.array_equal(tid, ia)
+    other_oracle.close()
+    other.close()
+
+
 def _limits(tc, seed):
     """distance limits that probe the reference's `dist - length >= -EPSILON` rule: the hit distance
     itself, one ulp and a few 1e-5 steps either side of it, far beyond, far short, zero, infinity"""
@@ -555,3 +587,72 @@ def test_path_list_visibility(cornell, cornell_oracle, ra):
         assert np.array_equal(g.ravel()[both], vc.astype(bool))
         checked += int(both.sum())
     assert checked > 2000  # connections compared
+
+
+def test_axis_parallel_batch_is_not_a_hang(gpu, cornell, cornell_oracle, ra):
+    """A whole batch outside the classifier's model (every ray exactly axis-parallel, as an orthographic camera
+    makes them): the fast walk skips every ray, k_verify lists all of them, and the list goes to the lane-per-ray
+    exact kernel because it is longer than k_rerun (one wave per ray) takes. Bit-equal to the oracle, and in a
+    time that shows nobody walked 2 Mi rays one wave at a time."""
+    import time
+
+    import torch
+
+    gpu.upload(cornell.describe())
+    n = 1 << 21
+    rng = np.random.default_rng(5)
+    o = rng.uniform(-0.95, 0.95, (3, n)).astype(np.float32)
+    o[2] = 1.5
+    d = np.zeros((3, n), np.float32)
+    d[2] = -1.0
+    aux = ra.pack_ids(np.full(n, -1), np.full(n, -1))
+    to, td, ta = (torch.from_numpy(x).cuda() for x in (o, d, aux))
+    t = torch.empty(n, dtype=torch.float32, device="cuda")
+    i = torch.empty(n, dtype=torch.int32, device="cuda")
+    for rep in range(2):  # (the first call sizes the list buffer)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gpu.intersect_dev(to.data_ptr(), td.data_ptr(), ta.data_ptr(), n, ra.MODE_NO_SELF, t.data_ptr(), i.data_ptr())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    tc, ic = cornell_oracle.intersect(o, d, aux, ra.MODE_NO_SELF, threads=16)
+    assert np.array_equal(i.cpu().numpy(), ic) and np.array_equal(t.cpu().numpy(), tc)
+    assert (ic >= 0).mean() > 0.9
+    assert dt < 0.25, "2 Mi axis-parallel rays took %.3f s" % dt
+
+
+def test_grazing_rays_divergence_is_bounded(gpu, cornell, cornell_oracle, ra):
+    """The traversal skips a subtree whose slab entry distance lies beyond best * 1.0001 + 1e-5. That slack is
+    a heuristic between the plane-equation t and the slab distance: for a triangle met at a grazing angle
+    (|n.d| tiny) the rounded t = orthoDist / (n.d) can be off by more than the slack, and the reference (which
+    prunes nothing) may then prefer a triangle whose box the kernel skipped. This is the one tolerated
+    divergence of the closest-hit path; here rays built to graze the walls at 1e-3 .. 1e-6 rad must
+    stay within the north star's bar, and every differing ray must be such a grazing case."""
+    n = 400000
+    rng = np.random.default_rng(12)
+    o = rng.uniform(-0.9, 0.9, (3, n))
+    d = rng.normal(size=(3, n))
+    axis = rng.integers(0, 3, n)
+    eps = 10.0 ** rng.uniform(-6, -3, n) * rng.choice([-1.0, 1.0], n)
+    d[axis, np.arange(n)] = eps  # nearly parallel to the two walls perpendicular to `axis`
+    o[axis, np.arange(n)] = rng.choice([-1.0, 1.0], n) * (1.0 - np.abs(eps) * rng.uniform(0, 2, n))  # skimming them
+    d /= np.linalg.norm(d, axis=0, keepdims=True)
+    o, d = o.astype(np.float32), d.astype(np.float32)
+    aux = ra.pack_ids(np.full(n, -1), np.full(n, -1))
+    gpu.upload(cornell.describe())
+    raw = cornell.raw()
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_NO_SELF, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = cornell_oracle.intersect(o, d, a, mode, threads=16)
+        diff = np.nonzero(ig != ic)[0]
+        assert len(diff) <= 1e-4 * n, "mode %d: %d of %d grazing rays differ" % (mode, len(diff), n)
+        for k in diff:  # each is a grazing hit on either side
+            worst = 1.0
+            for tid in (ig[k], ic[k]):
+                if tid < 0:
+                    continue
+                v = raw["verts"][raw["tris"][tid].astype(np.int64)].astype(np.float64)
+                nn = np.cross(v[1] - v[0], v[2] - v[1])
+                nn /= np.linalg.norm(nn)
+                worst = min(worst, abs(float(nn @ d[:, k].astype(np.float64))))
+            assert worst < 1e-3, (k, ig[k], ic[k], tg[k], tc[k], worst)

@@ -42,6 +42,19 @@ def test_no_gpu_means_error_not_fallback(ra):
         ra.Device(device=0)
 
 
+def test_no_scene_is_resident_without_a_device(cornell, mesh20k, ra):
+    """IntersectionHIP records which scene it holds; without a context none is, and host-only edits of a
+    scene (set_textures) re-stamp it (the device copy, if any, no longer describes it)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert ra.lib().mirth_is_resident(cornell.h) == 0 and ra.lib().mirth_is_resident(mesh20k.h) == 0
+    assert ra.lib().mirth_is_resident(None) == 0
+    with pytest.raises(ra.MirtError):  # a query uploads first, and that fails loudly without a GPU
+        cornell.fill_intersect(np.zeros((1, 3), np.float32), np.ones((1, 3), np.float32), [-1], [-1])
+
+
 def test_config_load_cornell(cornell, ra):
     assert (cornell.n_objects, cornell.n_tris, cornell.n_verts) == (8, 1932, 988)
     raw = cornell.raw()
