@@ -213,6 +213,20 @@ int mirt_intersect(MirtContext* ctx, const float* origins, const float* directio
 int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* directions,
                        const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
                        void* stream);
+/* The same call for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc). It has no counterpart in the reference. It calls no hipMalloc / hipFree / event or
+ * stream creation and never synchronises: the three scratch buffers mirt_intersect_dev keeps in hipMalloc'd
+ * memory (the ray-queue words, the list of rays handed to the exact re-run, the traversal-stack levels beyond the
+ * LDS share) live in ONE static device array of 48 MiB + 256 B that every GPU the library runs on holds until the
+ * process ends. Limits: n <= MIRT_NOALLOC_MAX_RAYS per call (MIRT_E_LIMIT beyond it); the persistent grid is cut
+ * down until its deep stack levels fit 32 MiB (same answers, fewer waves on very deep trees). Modes 0 / 1 take
+ * the route an earlier mirt_intersect_dev call settled on for the scene, else the reference tree alone (no timing
+ * here). Every call on a GPU shares that GPU's array (all contexts on it too): calls that overlap on one GPU RACE -
+ * serialise them (one stream, or events). Results are bit-identical to mirt_intersect_dev's.              */
+#define MIRT_NOALLOC_MAX_RAYS (4u << 20)
+int mirt_intersect_noalloc_dev(MirtContext* ctx, const float* origins, const float* directions,
+                               const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
+                               void* stream);
 /* --- batched visibility ---------------------------------------------------------------------
  * replaces MCRenderer::testVisibility (MCRenderer.cpp:106-118) for a batch: visible[i] = 1 when the
  * closest hit under `mode` (normally MIRT_MODE_NO_SELF, aux as above) does not exist or satisfies

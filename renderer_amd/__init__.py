@@ -17,6 +17,7 @@ DATA_DIR = os.path.join(REPO_ROOT, "Data")
 
 OBJ_DIFFUSE, OBJ_GLOSSY, OBJ_REFRACTIVE, OBJ_EMISSIVE, OBJ_VPM, OBJ_PHONG = range(6)
 MODE_UNCONDITIONAL, MODE_LAST_TID, MODE_NO_SELF = range(3)
+NOALLOC_MAX_RAYS = 4 << 20  # MIRT_NOALLOC_MAX_RAYS
 
 # MirtObject as a numpy structured dtype (same layout as the C struct; also the oracle's OrcObject)
 OBJECT_DTYPE = np.dtype(
@@ -86,7 +87,7 @@ def texture_structs(textures):
 
 # every symbol include/mirt.h and include/mirt_host.h declare (checked by the CPU tests)
 MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_scene", "mirt_scene_serial", "mirt_intersect",
-                "mirt_intersect_dev", "mirt_visibility", "mirt_visibility_dev", "mirt_fast_tree", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
+                "mirt_intersect_dev", "mirt_intersect_noalloc_dev", "mirt_visibility", "mirt_visibility_dev", "mirt_fast_tree", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
                 "mirt_render_pt_dev", "mirt_render_pttest", "mirt_render_pttest_dev", "mirt_capture_rays_dev", "mirt_device_info"]
 MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_set_textures", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
@@ -129,6 +130,7 @@ def lib():
         L.mirt_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                      C.c_void_p, C.c_void_p]
         L.mirt_intersect_dev.argtypes = L.mirt_intersect.argtypes + [C.c_void_p]
+        L.mirt_intersect_noalloc_dev.argtypes = L.mirt_intersect_dev.argtypes
         L.mirt_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_int, C.c_void_p]
         L.mirt_visibility_dev.argtypes = L.mirt_visibility.argtypes + [C.c_void_p]
@@ -454,6 +456,10 @@ class Device:
 
     def intersect_dev(self, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr, stream=None):
         self._check(lib().mirt_intersect_dev(self.ctx, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr, stream))
+
+    def intersect_noalloc_dev(self, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr, stream=None):
+        """mirt_intersect_noalloc_dev: same answers, scratch from the static device array, n <= NOALLOC_MAX_RAYS"""
+        self._check(lib().mirt_intersect_noalloc_dev(self.ctx, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr, stream))
 
     def intersect_count_dev(self, o_ptr, d_ptr, aux_ptr, n, mode, t_ptr, tid_ptr):
         nb, nt = C.c_uint64(), C.c_uint64()

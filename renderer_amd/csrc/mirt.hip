@@ -34,6 +34,7 @@ struct MirtContext {
     DevScene sc{};
     bool has_scene = false;
     uint64_t scene_serial = 0; // successful uploads so far (mirt_scene_serial)
+    unsigned char* d_scratch = nullptr;  // this device's copy of `scratch` (hipGetSymbolAddress in mirt_create)
     bool has_media = false;    // scene holds a homogeneous medium (MIRT_OBJ_VPM)
     bool media_ready = true;   // ... and every such object came with its own tree
     VolRoot* d_vols = nullptr;
@@ -101,6 +102,20 @@ struct MirtContext {
 
 static thread_local std::string g_create_err;
 
+// ---- static device scratch of mirt_intersect_noalloc_dev (include/mirt.h) ---------------------------
+// Callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc) get the
+// closest-hit call's three scratch buffers from this file-scope array instead of hipMalloc'd memory: every GPU the
+// library runs on holds its own copy at its own address until the process ends. In host code the array's NAME
+// is only a stand-in for hipGetSymbolAddress; mirt_create resolves the address once per context, with the
+// context's device current, and everything below uses that pointer (kernel arguments, hipMemsetAsync).
+//   [0, 256)                         queue head of the fast launch, list length, queue head of the exact launch
+//   [256, 256 + 4 * MAX_RAYS)        ray indices k_verify hands to the exact re-run
+//   [.., + NOALLOC_SPILL_BYTES)      stack levels beyond the LDS share (the grid is cut down until they fit)
+constexpr size_t NOALLOC_QUEUE_BYTES = 256;
+constexpr size_t NOALLOC_LIST_BYTES = (size_t)MIRT_NOALLOC_MAX_RAYS * sizeof(uint32_t);
+constexpr size_t NOALLOC_SPILL_BYTES = (size_t)32 << 20;
+constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_QUEUE_BYTES + NOALLOC_LIST_BYTES + NOALLOC_SPILL_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
 #define HIPCHK(ctx, call)                                                                       \
     do {                                                                                        \
@@ -178,6 +193,13 @@ int mirt_create(int device, MirtContext** out) {
                  prop.totalGlobalMem / 1073741824.0);
         ctx->info = buf;
         ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // this device's address of the static scratch array (the array's name itself is no device address)
+    if ((e = hipGetSymbolAddress((void**)&ctx->d_scratch, HIP_SYMBOL(scratch))) != hipSuccess || !ctx->d_scratch) {
+        g_create_err = std::string("mirt_create: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return MIRT_E_HIP;
     }
     if ((e = hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc(&ctx->d_queue, 64 * sizeof(uint32_t))) != hipSuccess) {
@@ -1374,6 +1396,37 @@ int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* dire
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     return launch_intersect<false, false>(ctx, st, mode, origins, directions, aux, (uint32_t)n,
                                           (uint32_t)n, t_out, tid_out);
+}
+
+// mirt_intersect_dev without a single allocation: scratch from this device's copy of the static array.
+int mirt_intersect_noalloc_dev(MirtContext* ctx, const float* origins, const float* directions,
+                               const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
+                               void* stream) {
+    int rc = check_intersect_args(ctx, origins, directions, aux, n, mode, t_out, tid_out);
+    if (rc != MIRT_OK || n == 0) return rc;
+    if (n > MIRT_NOALLOC_MAX_RAYS)
+        return fail(ctx, MIRT_E_LIMIT, "intersect_noalloc: more than MIRT_NOALLOC_MAX_RAYS (4 Mi) rays in one call");
+    if (!ctx->d_scratch) return fail(ctx, MIRT_E_HIP, "intersect_noalloc: the static scratch array was not resolved");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    LaunchBufs lb;
+    uint32_t* qwords = reinterpret_cast<uint32_t*>(ctx->d_scratch);
+    lb.list = reinterpret_cast<uint32_t*>(ctx->d_scratch + NOALLOC_QUEUE_BYTES);
+    lb.spill = reinterpret_cast<uint2*>(ctx->d_scratch + NOALLOC_QUEUE_BYTES + NOALLOC_LIST_BYTES);
+    // the persistent grid, cut down until the stack levels beyond the LDS share fit the spill slice
+    auto cap = [&](int max_blocks, uint32_t lds_levels) -> uint32_t {
+        const size_t deep = (size_t)ctx->sc.depth + 1 > lds_levels ? (size_t)ctx->sc.depth + 1 - lds_levels : 0;
+        if (deep == 0) return (uint32_t)max_blocks;
+        return (uint32_t)std::min<size_t>((size_t)max_blocks, NOALLOC_SPILL_BYTES / (deep * (size_t)ctx->block * sizeof(uint2)));
+    };
+    lb.max_blocks = cap(ctx->max_blocks, ctx->lds_levels);
+    lb.max_blocks_fast = cap(ctx->max_blocks_fast, ctx->lds_levels_fast);
+    if (lb.max_blocks == 0 || lb.max_blocks_fast == 0)
+        return fail(ctx, MIRT_E_LIMIT, "intersect_noalloc: the tree is too deep for the static spill area");
+    // the array keeps the last call's contents: the three queue / count words must start at zero
+    HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
+    return launch_intersect<false, false>(ctx, st, mode, origins, directions, aux, (uint32_t)n, (uint32_t)n, t_out, tid_out,
+                                          nullptr, qwords, false, &lb);
 }
 
 int mirt_intersect_audit_dev(MirtContext* ctx, const float* origins, const float* directions,
