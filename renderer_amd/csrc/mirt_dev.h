@@ -276,12 +276,16 @@ __device__ __forceinline__ int slab_classify(const float4 lo, const float4 hi, b
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct RayPre2 {
     v2f oxy, ixy, ozi;  // origin / reciprocal direction as register pairs (halves broadcast by op_sel); ozi = (o.z, 1/d.z)
+    v2f cxy;            // slab_miss_pair: (-o.x / d.x, -o.y / d.y) as RN(-o * RN(1/d)), and cz likewise
+    float cz;
 };
 __device__ __forceinline__ RayPre2 ray_pairs(f3 o, const RayPre& p) {
     RayPre2 q;
     q.oxy = v2f{o.x, o.y};
     q.ixy = v2f{p.inv.x, p.inv.y};
     q.ozi = v2f{o.z, p.inv.z};
+    q.cxy = v2f{-o.x * p.inv.x, -o.y * p.inv.y};
+    q.cz = -o.z * p.inv.z;
     return q;
 }
 __device__ __forceinline__ int slab_classify_pair(const float4 a, const float4 b, const RayPre2& q,
@@ -305,6 +309,31 @@ __device__ __forceinline__ int slab_classify_pair(const float4 a, const float4 b
     const bool hit = ok_gap & (tf >= 0.f) & (e > M);
     const bool miss = (tf < -M) | (fminf(fminf(-gap, e_top), e_bot) > M) | (on_flat & (tf < 0.f));
     return hit ? BOX_HIT : (miss ? BOX_MISS : BOX_AMBIGUOUS);
+}
+// The fast tree's box test (k_intersect<FAST>): it only has to be CONSERVATIVE, i.e. report a miss only when the
+// reference test (KDTree.cpp:34-52) provably rejects the box; everything else is entered and k_verify sorts it out.
+// So no hit is proven here and the slab parameters come from one fused multiply-add per plane,
+//     t~ = RN(P * y + c),  y = RN(1/d),  c = RN(-o * y):   |t~ - (P - o)/d| <= 3 eps (|P| + |o|) |y|,
+// which the absolute part of the margin covers (a_ray = 16 eps max_a (|o_a| + bound_a) |y_a|, every |P| <= bound).
+// MISS is reported when the box lies wholly behind the origin (tf < -M) or the three slab intervals are disjoint by
+// more than M (tn - tf > M): a face the reference accepted would have its parameter t inside all three slabs up to
+// the reference's own rounding (eps (|o_b| + |P_b|) / |d_b| + 2 eps |t| per compare, in t units), hence
+// tn - err <= t <= tf + err, which tn - tf > M >= 2 err excludes. `unproven` tells the caller that the box was
+// entered only because of the margin (|tf - tn| <= M on a box that is not flat): a ray for which that keeps
+// happening (a nearly axis-parallel direction makes M enormous) is given up and left to the exact kernel.
+__device__ __forceinline__ bool slab_miss_pair(const float4 a, const float4 b, const RayPre2& q, const RayPre& p,
+                                               float& lb, bool& unproven) {
+    const v2f tx = __builtin_elementwise_fma(v2f{a.x, a.y}, q.ixy.xx, q.cxy.xx);
+    const v2f ty = __builtin_elementwise_fma(v2f{a.z, a.w}, q.ixy.yy, q.cxy.yy);
+    const v2f tz = __builtin_elementwise_fma(v2f{b.x, b.y}, q.ozi.yy, v2f{q.cz, q.cz});
+    const float tn = fmaxf(fminf(tx.x, tx.y), fmaxf(fminf(ty.x, ty.y), fminf(tz.x, tz.y)));
+    const float tf = fminf(fmaxf(tx.x, tx.y), fminf(fmaxf(ty.x, ty.y), fmaxf(tz.x, tz.y)));
+    const float M = __builtin_fmaf(1.9073486e-06f /*32 * 2^-24*/, fabsf(tn) + fabsf(tf), p.a_ray);
+    const float gap = tf - tn;
+    lb = fmaxf(tn, 0.f);
+    const bool miss = (tf < -M) | (gap < -M);
+    unproven = !miss & (__float_as_int(b.w) == 0) & !(gap > M);
+    return miss;
 }
 __device__ __forceinline__ bool box_is_flat(const float4 lo, const float4 hi) {
     return (lo.x == hi.x) | (lo.y == hi.y) | (lo.z == hi.z);

@@ -360,6 +360,30 @@ def test_classifier_audit_adversarial(gpu, cornell, mesh20k, ra):
             assert a["ambiguous"] > 1000  # these rays do reach the unproven zone
 
 
+def test_fast_tree_miss_test_is_conservative(gpu, cornell, mesh20k, ra, monkeypatch):
+    """The fast tree's box test (slab_miss_pair: one fused multiply-add per plane, no hit proof) may only report a
+    miss that the reference test shares. The instrumented fast route (MIRT_AUDIT_FAST) evaluates the reference
+    box test beside every reported miss and counts the disagreements: zero, on random, surface-skimming,
+    near-axis-parallel and corner / edge-aimed rays."""
+    import torch
+
+    monkeypatch.setenv("MIRT_AUDIT_FAST", "1")
+    for scene, inside in ((cornell, 2), (mesh20k, 8)):
+        gpu.upload(scene.describe())
+        n = 1 << 20
+        o, d, aux = meshgen.random_rays(n, 93, scene.n_objects, inside_obj=inside)
+        oa, da = _adversarial_rays(scene, n // 2, 23)
+        o[:, : n // 2], d[:, : n // 2] = oa, da
+        to, do_, ta = (torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (o, d, aux))
+        tt = torch.empty(n, dtype=torch.float32, device="cuda")
+        ti = torch.empty(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for mode in (2, 0):
+            a = gpu.intersect_audit_dev(to.data_ptr(), do_.data_ptr(), ta.data_ptr(), n, mode, tt.data_ptr(), ti.data_ptr())
+            assert a["mismatch"] == 0, a
+            assert a["box"] > 10 * n
+
+
 def test_device_pointer_entry_and_streams(cornell_dev, cornell, cornell_oracle, ra):
     import torch
 
