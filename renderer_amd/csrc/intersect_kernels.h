@@ -654,6 +654,7 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
         const f3 o = mk3(O[i], O[plane_stride + i], O[2 * plane_stride + i]);
         const f3 d = mk3(D[i], D[plane_stride + i], D[2 * plane_stride + i]);
         const RayPre pre = ray_prepare(sc, o, d);
+        const f3 c = mk3(-o.x * pre.inv.x, -o.y * pre.inv.y, -o.z * pre.inv.z);
         const int slot = id_out[i];
         if (!pre.fast) {
             redo = true;
@@ -669,12 +670,18 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
                     break;
                 }
                 const NodeRec N = sc.rnodes[node];
-                float lb;
-                const int code = slab_classify(N.lo, N.hi, __float_as_int(N.hi.w) != 0, o, pre, lb);
                 if (COUNT) boxes++;
-                if (code != BOX_HIT && !(code == BOX_AMBIGUOUS && box_test(N.lo, N.hi, o, d).hit)) {
-                    redo = true;
-                    break;
+                // most boxes of a chain are left through a face well clear of the box's edges: proven in ~25
+                // instructions; the rest (and every flat box) takes the full classifier, then the reference test
+                if (!slab_exit_face_proven(N.lo, N.hi, c, pre)) {
+                    float lb;
+                    const int code = slab_classify(N.lo, N.hi, __float_as_int(N.hi.w) != 0, o, pre, lb);
+                    if (code != BOX_HIT && !(code == BOX_AMBIGUOUS && box_test(N.lo, N.hi, o, d).hit)) {
+                        redo = true;
+                        break;
+                    }
+                } else if (COUNT && !box_test(N.lo, N.hi, o, d).hit) {
+                    atomicAdd(&counters[3], 1ull);  // audit: a proven exit face the reference test does not share (must be 0)
                 }
                 node = __float_as_int(N.lo.w);
             }

@@ -1042,6 +1042,13 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
                                                          ctx->block, ctx->lds_main_fast) == hipSuccess && occ >= 1)
             ctx->max_blocks_fast = occ * ctx->n_cus;
     }
+    if (const char* e = getenv("MIRT_GRID_SCALE")) {  // experiment: leave wave slots free for another context's launches
+        const double f = atof(e);
+        if (f > 0.05 && f <= 1.0) {
+            ctx->max_blocks = std::max(1, (int)(ctx->max_blocks * f));
+            ctx->max_blocks_fast = std::max(1, (int)(ctx->max_blocks_fast * f));
+        }
+    }
     // one spill area serves both configurations (launches on a handle do not overlap)
     const size_t spill_a = ((size_t)depth + 1 - ctx->lds_levels) * (size_t)ctx->max_blocks;
     const size_t spill_b = ((size_t)depth + 1 - ctx->lds_levels_fast) * (size_t)ctx->max_blocks_fast;

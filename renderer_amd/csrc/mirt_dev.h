@@ -335,6 +335,23 @@ __device__ __forceinline__ bool slab_miss_pair(const float4 a, const float4 b, c
     unproven = !miss & (__float_as_int(b.w) == 0) & !(gap > M);
     return miss;
 }
+// k_verify's first look at a box of the winner's chain: a SUFFICIENT condition for "the reference test passes",
+// cheaper than the full classifier. With the slab parameters of slab_miss_pair (one fused multiply-add per plane;
+// c = RN(-o * RN(1/d)) per axis), the reference accepts the EXIT face when that face lies in front of the origin
+// (tf > M), the box is entered before it is left by more than the margin (tf - tn > M: the exit point is inside the
+// other two slabs on their entry side) and the exit is clear of the other two axes' exits (f2 - tf > M: inside them
+// on their exit side). The rounding of these t~ is within 3/16 of a_ray each, so differences of two of them and the
+// reference's own compare error still fit M. A box that fails this (flat boxes always do) goes to slab_classify.
+__device__ __forceinline__ bool slab_exit_face_proven(const float4 lo, const float4 hi, f3 c, const RayPre& p) {
+    const float t0x = __builtin_fmaf(lo.x, p.inv.x, c.x), t1x = __builtin_fmaf(hi.x, p.inv.x, c.x);
+    const float t0y = __builtin_fmaf(lo.y, p.inv.y, c.y), t1y = __builtin_fmaf(hi.y, p.inv.y, c.y);
+    const float t0z = __builtin_fmaf(lo.z, p.inv.z, c.z), t1z = __builtin_fmaf(hi.z, p.inv.z, c.z);
+    const float fx = fmaxf(t0x, t1x), fy = fmaxf(t0y, t1y), fz = fmaxf(t0z, t1z);
+    const float tn = fmaxf(fminf(t0x, t1x), fmaxf(fminf(t0y, t1y), fminf(t0z, t1z)));
+    const float tf = fminf(fx, fminf(fy, fz)), f2 = __builtin_amdgcn_fmed3f(fx, fy, fz);
+    const float M = __builtin_fmaf(1.9073486e-06f /*32 * 2^-24*/, fabsf(tn) + fabsf(tf), p.a_ray);
+    return (tf > M) & (tf - tn > M) & (f2 - tf > M);
+}
 __device__ __forceinline__ bool box_is_flat(const float4 lo, const float4 hi) {
     return (lo.x == hi.x) | (lo.y == hi.y) | (lo.z == hi.z);
 }
