@@ -292,6 +292,24 @@ int mirt_render_pttest(MirtContext* ctx, const MirtRenderParams* params, float* 
 int mirt_render_pttest_dev(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
                            MirtRenderStats* stats /* may be NULL */);
 
+/* --- several GPUs -----------------------------------------------------------------------------
+ * The same seam (MCRenderer::renderPixels as Renderer::render calls it, MCRenderer.h:114-117, Renderer.cpp:46-50) over
+ * n_ctx contexts, normally one per GPU (several on one device work too). The reference has no counterpart: its only
+ * parallelism is OpenMP over pixels (PathTracer.cpp:17). Every context must hold the same scene (mirt_upload_scene on
+ * each). The call's samples [spp_begin, spp_begin + spp_count) are cut into n_ctx contiguous shards (the first
+ * spp_count % n_ctx shards get one sample more); every context renders its shard into its own device accumulator, from
+ * its own host thread; the accumulators are then summed on ctxs[0]'s device in context order (peer copy + add kernel:
+ * W*H*3 floats per context, 12 MiB at 1024^2) and the total lands in the HOST buffer rgb_sum, which is overwritten.
+ * Sample streams are keyed by the global sample index, so the image equals the one-context image up to fp32 summation
+ * order. stats: n_samples / n_rays / n_shadow_rays / intersect_ms summed, gpu_ms = the slowest context's.
+ * Calls on the contexts involved must not overlap with other calls on them.                                       */
+int mirt_render_pt_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, float* rgb_sum,
+                         MirtRenderStats* stats /* may be NULL */);
+int mirt_render_pttest_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, float* rgb_sum,
+                             MirtRenderStats* stats /* may be NULL */);
+/* number of HIP devices (0 when there is none; never an error) */
+int mirt_device_count(void);
+
 /* Secondary-ray capture for the closest-hit benchmark: run the path tracer
  * for spp_count samples and copy out every secondary ray (origin, direction, packed ids) issued at
  * bounce depths [depth_lo, depth_hi]. DEVICE pointers; capacity in rays; *n_captured on host.  */

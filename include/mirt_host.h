@@ -81,6 +81,9 @@ int mirth_test_path_list_visibility(MirthScene* s, int32_t n_paths, const int32_
 void mirth_world_vertex(const float m[16], const float v[3], float out[3]);
 void mirth_normal_transform(const float m[16], const float vn[3], float out[3]);
 void mirth_shutdown(void);
+/* Renders go to these devices from now on (IntersectionHIP::setDevices: devices[0] is the service's own device, a
+ * device may be listed twice; n = 0 or 1: single GPU): sample shards + one reduce through mirt_render_pt_multi.    */
+int mirth_set_devices(const int32_t* devices, int32_t n);
 /* 1 when this scene is the one the shared device service holds (IntersectionHIP::isResident: same Scene, same
  * build of its tree and textures, nobody uploaded through the context since), else 0. Queries made through a
  * scene check this themselves and upload again when needed; exported for tests and tools.            */

@@ -88,11 +88,12 @@ def texture_structs(textures):
 # every symbol include/mirt.h and include/mirt_host.h declare (checked by the CPU tests)
 MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_scene", "mirt_scene_serial", "mirt_intersect",
                 "mirt_intersect_dev", "mirt_intersect_noalloc_dev", "mirt_visibility", "mirt_visibility_dev", "mirt_fast_tree", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
-                "mirt_render_pt_dev", "mirt_render_pttest", "mirt_render_pttest_dev", "mirt_capture_rays_dev", "mirt_device_info"]
+                "mirt_render_pt_dev", "mirt_render_pttest", "mirt_render_pttest_dev", "mirt_render_pt_multi", "mirt_render_pttest_multi", "mirt_device_count",
+                "mirt_capture_rays_dev", "mirt_device_info"]
 MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_set_textures", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
                  "mirth_describe", "mirth_upload", "mirth_render", "mirth_render_progressive", "mirth_fill_intersect", "mirth_test_visibility", "mirth_test_path_list_visibility", "mirth_world_vertex", "mirth_normal_transform",
-                 "mirth_shutdown", "mirth_is_resident",
+                 "mirth_shutdown", "mirth_is_resident", "mirth_set_devices",
                  "mirth_save_pfm", "mirth_load_pfm"]
 
 _lib = None
@@ -144,6 +145,11 @@ def lib():
         L.mirt_render_pt_dev.argtypes = L.mirt_render_pt.argtypes
         L.mirt_render_pttest.argtypes = L.mirt_render_pt.argtypes
         L.mirt_render_pttest_dev.argtypes = L.mirt_render_pt.argtypes
+        L.mirt_render_pt_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RenderParams), C.c_void_p,
+                                           C.POINTER(RenderStats)]
+        L.mirt_render_pttest_multi.argtypes = L.mirt_render_pt_multi.argtypes
+        L.mirt_device_count.argtypes = []
+        L.mirth_set_devices.argtypes = [C.c_void_p, C.c_int32]
         L.mirt_capture_rays_dev.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.c_uint32,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.POINTER(C.c_size_t)]
@@ -513,6 +519,27 @@ class Device:
         self._check(lib().mirt_capture_rays_dev(self.ctx, C.byref(p), depth_lo, depth_hi, o_ptr, d_ptr, aux_ptr,
                                                 capacity, C.byref(n)))
         return n.value
+
+
+def render_pt_multi(devices, cam, spp_count, spp_begin=0, max_depth=20, seed=1, spp_per_launch=0, pttest=False):
+    """mirt_render_pt_multi over a list of Device objects (each holding the scene): contiguous sample shards, one
+    reduce on devices[0]'s GPU. Returns (rgb_sum [H, W, 3] float32 on the host, RenderStats)."""
+    p = RenderParams(cam, spp_begin, spp_count, max_depth, seed, spp_per_launch)
+    img = np.zeros((cam.height, cam.width, 3), np.float32)
+    st = RenderStats()
+    arr = (C.c_void_p * len(devices))(*[d.ctx for d in devices])
+    fn = lib().mirt_render_pttest_multi if pttest else lib().mirt_render_pt_multi
+    rc = fn(arr, len(devices), C.byref(p), _ptr(img), C.byref(st))
+    if rc != 0:
+        raise MirtError("mirt error %d: %s" % (rc, lib().mirt_last_error(devices[0].ctx).decode()))
+    return img, st
+
+
+def set_devices(devices):
+    """IntersectionHIP::setDevices: the host surface's renders (HostScene.render ...) use these GPUs from now on."""
+    arr = np.ascontiguousarray(devices, np.int32)
+    if lib().mirth_set_devices(_ptr(arr), len(arr)) != 0:
+        raise MirtError(lib().mirth_last_error().decode())
 
 
 def make_camera(width, height, sight_dist, position=(0, 0, 2), focus=(0, 0, 0), up=(0, 1, 0)):

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "intersect_kernels.h"
@@ -1924,6 +1925,112 @@ int mirt_render_pttest(MirtContext* ctx, const MirtRenderParams* params, float* 
     }
     hipFree(d_rgb);
     return rc;
+}
+
+int mirt_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
+// Sample shards over several contexts + one reduce (include/mirt.h). One host thread per context: a render call
+// blocks on its own stream now and then (live-path counts), and the contexts' devices run independently.
+static int render_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, float* rgb_sum,
+                        MirtRenderStats* stats, bool nee) {
+    if (stats) *stats = MirtRenderStats{};
+    if (!ctxs || n_ctx <= 0 || !ctxs[0]) return MIRT_E_INVALID;
+    MirtContext* c0 = ctxs[0];
+    if (!params || !rgb_sum) return fail(c0, MIRT_E_INVALID, "render_multi: NULL argument");
+    for (int k = 0; k < n_ctx; k++) {
+        if (!ctxs[k]) return fail(c0, MIRT_E_INVALID, "render_multi: NULL context");
+        for (int j = 0; j < k; j++)
+            if (ctxs[j] == ctxs[k]) return fail(c0, MIRT_E_INVALID, "render_multi: the same context twice");
+        if (!ctxs[k]->has_scene) return fail(c0, MIRT_E_NO_SCENE, "render_multi: a context holds no scene");
+    }
+    if (params->camera.width <= 0 || params->camera.height <= 0)
+        return fail(c0, MIRT_E_INVALID, "camera: width/height must be positive");
+    const size_t count = (size_t)params->camera.width * params->camera.height * 3, bytes = count * sizeof(float);
+    if (count > 0x7FFFFFFFull) return fail(c0, MIRT_E_LIMIT, "render_multi: image too large");
+    struct Shard {
+        MirtRenderParams prm;
+        MirtRenderStats st{};
+        float* acc = nullptr;
+        int rc = MIRT_OK;
+    };
+    std::vector<Shard> sh(n_ctx);
+    const uint32_t base = params->spp_count / (uint32_t)n_ctx, rem = params->spp_count % (uint32_t)n_ctx;
+    uint32_t begin = params->spp_begin;
+    for (int k = 0; k < n_ctx; k++) {  // contiguous shards; the same split as renderer_amd.shard_samples
+        sh[k].prm = *params;
+        sh[k].prm.spp_begin = begin;
+        sh[k].prm.spp_count = base + ((uint32_t)k < rem ? 1u : 0u);
+        begin += sh[k].prm.spp_count;
+    }
+    auto work = [&](int k) {
+        MirtContext* ctx = ctxs[k];
+        Shard& S = sh[k];
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipMalloc(&S.acc, bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(S.acc, 0, bytes, ctx->stream);
+        if (e != hipSuccess) {
+            S.rc = fail(ctx, MIRT_E_HIP, std::string("render_multi: ") + hipGetErrorString(e));
+            return;
+        }
+        if (S.prm.spp_count == 0) {  // more contexts than samples: an empty shard
+            e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) S.rc = fail(ctx, MIRT_E_HIP, hipGetErrorString(e));
+            return;
+        }
+        S.rc = render_common(ctx, &S.prm, S.acc, nullptr, &S.st, nee);
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < n_ctx; k++) threads.emplace_back(work, k);
+    work(0);
+    for (std::thread& t : threads) t.join();
+    int rc = MIRT_OK;
+    for (int k = 0; k < n_ctx && rc == MIRT_OK; k++)
+        if (sh[k].rc != MIRT_OK) {
+            rc = sh[k].rc;
+            if (k) c0->err = "render_multi: context " + std::to_string(k) + ": " + ctxs[k]->err;
+        }
+    // reduce on context 0's device, in context order (deterministic): peer copy into a staging buffer, then add
+    float* tmp = nullptr;
+    hipError_t e = hipSetDevice(c0->device);
+    if (rc == MIRT_OK && n_ctx > 1 && e == hipSuccess) e = hipMalloc(&tmp, bytes);
+    for (int k = 1; k < n_ctx && rc == MIRT_OK && e == hipSuccess; k++) {
+        e = hipMemcpyPeer(tmp, c0->device, sh[k].acc, ctxs[k]->device, bytes);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_add, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, c0->stream, sh[0].acc, (const float*)tmp,
+                           (uint32_t)count);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);  // tmp is reused by the next context
+    }
+    if (rc == MIRT_OK && e == hipSuccess) e = hipMemcpy(rgb_sum, sh[0].acc, bytes, hipMemcpyDeviceToHost);
+    if (rc == MIRT_OK && e != hipSuccess) rc = fail(c0, MIRT_E_HIP, std::string("render_multi: reduce: ") + hipGetErrorString(e));
+    hipFree(tmp);
+    for (int k = 0; k < n_ctx; k++) {
+        if (!sh[k].acc) continue;
+        hipSetDevice(ctxs[k]->device);
+        hipFree(sh[k].acc);
+    }
+    if (stats && rc == MIRT_OK)
+        for (int k = 0; k < n_ctx; k++) {
+            stats->n_samples += sh[k].st.n_samples;
+            stats->n_rays += sh[k].st.n_rays;
+            stats->n_shadow_rays += sh[k].st.n_shadow_rays;
+            stats->intersect_ms += sh[k].st.intersect_ms;
+            stats->gpu_ms = std::max(stats->gpu_ms, sh[k].st.gpu_ms);
+        }
+    return rc;
+}
+
+int mirt_render_pt_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, float* rgb_sum,
+                         MirtRenderStats* stats) {
+    return render_multi(ctxs, n_ctx, params, rgb_sum, stats, false);
+}
+
+int mirt_render_pttest_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, float* rgb_sum,
+                             MirtRenderStats* stats) {
+    return render_multi(ctxs, n_ctx, params, rgb_sum, stats, true);
 }
 
 int mirt_capture_rays_dev(MirtContext* ctx, const MirtRenderParams* params, uint32_t depth_lo,

@@ -914,4 +914,10 @@ k_accumulate(const float* __restrict__ L, uint32_t L_stride, uint32_t wh, uint32
     rgb_sum[3 * p + 2] += b;
 }
 
+// a[i] += b[i]: the reduce step of mirt_render_pt_multi (context k's radiance sums into context 0's)
+__global__ void __launch_bounds__(256) k_add(float* __restrict__ a, const float* __restrict__ b, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += b[i];
+}
+
 }  // namespace mirt

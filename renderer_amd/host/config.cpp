@@ -485,11 +485,16 @@ void PathTracerHIP::loadState(const std::string& fileName, const Camera& camera)
     resume = true;
 }
 
+// one context: mirt_render_pt; several (IntersectionHIP::setDevices): sample shards over all of them + one reduce
 int PathTracerHIP::launch(MirtContext* ctx, const MirtRenderParams* p, float* rgb_sum, MirtRenderStats* stats) {
+    const std::vector<MirtContext*>& all = IntersectionHIP::contexts();
+    if (all.size() > 1 && all[0] == ctx) return mirt_render_pt_multi(all.data(), (int)all.size(), p, rgb_sum, stats);
     return mirt_render_pt(ctx, p, rgb_sum, stats);
 }
 
 int PathTracerTestHIP::launch(MirtContext* ctx, const MirtRenderParams* p, float* rgb_sum, MirtRenderStats* stats) {
+    const std::vector<MirtContext*>& all = IntersectionHIP::contexts();
+    if (all.size() > 1 && all[0] == ctx) return mirt_render_pttest_multi(all.data(), (int)all.size(), p, rgb_sum, stats);
     return mirt_render_pttest(ctx, p, rgb_sum, stats);
 }
 

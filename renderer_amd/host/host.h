@@ -174,6 +174,12 @@ public:
     static void init(int device = 0);
     static void shutdown();
     static MirtContext* context();
+    // Several GPUs (the reference has one GL context, IntersectionGPU.cpp:16-44): one more context per listed device
+    // BESIDE the first, which stays the one batch queries go to. devices[0] must be the device init() was (or will be)
+    // called with; a device may be listed twice. loadKDTreeToDevice uploads to all of them, and PathTracerHIP then
+    // renders through mirt_render_pt_multi (sample shards + one reduce). An empty list or one entry = single GPU.
+    static void setDevices(const std::vector<int>& devices);
+    static const std::vector<MirtContext*>& contexts();  // [0] == context()
     static void loadKDTreeToDevice(const Scene& scene);
     // The service holds ONE scene at a time (like the reference's static GL state, IntersectionGPU.cpp:5-14).
     // loadKDTreeToDevice records which (the Scene and the generation of its tree); every query made through a

@@ -400,6 +400,11 @@ void mirth_normal_transform(const float m[16], const float vn[3], float out[3]) 
 
 void mirth_shutdown(void) { IntersectionHIP::shutdown(); }
 
+int mirth_set_devices(const int32_t* devices, int32_t n) {
+    if (n < 0 || (n > 0 && !devices)) return -1;
+    GUARD({ IntersectionHIP::setDevices(std::vector<int>(devices, devices + n)); })
+}
+
 int mirth_is_resident(const MirthScene* s) { return s && IntersectionHIP::isResident(s->renderer.scene) ? 1 : 0; }
 
 int mirth_save_pfm(const char* path, const float* rgb, int32_t w, int32_t h) {

@@ -26,14 +26,35 @@ static unsigned long long g_resident_gen = 0;    // ... and which build of it
 static uint64_t g_resident_serial = 0;           // mirt_scene_serial right after that upload (someone else may upload through the context)
 static unsigned long long g_next_generation = 0; // stamps handed to Scene::buildKDTree
 
+static std::vector<MirtContext*> g_all;  // g_ctx first, then the extra contexts of setDevices
+
 void IntersectionHIP::init(int device) {
     if (g_ctx) return;
     int rc = mirt_create(device, &g_ctx);
     if (rc != MIRT_OK)
         throw std::runtime_error(std::string("IntersectionHIP::init: ") + mirt_last_error(nullptr));
+    g_all.assign(1, g_ctx);
 }
 
+void IntersectionHIP::setDevices(const std::vector<int>& devices) {
+    init(devices.empty() ? 0 : devices[0]);
+    for (size_t k = 1; k < g_all.size(); k++) mirt_destroy(g_all[k]);
+    g_all.assign(1, g_ctx);
+    g_resident = nullptr;  // the new contexts hold no scene yet: the next query / render uploads to all
+    g_resident_gen = 0;
+    for (size_t k = 1; k < devices.size(); k++) {
+        MirtContext* c = nullptr;
+        if (mirt_create(devices[k], &c) != MIRT_OK)
+            throw std::runtime_error(std::string("IntersectionHIP::setDevices: ") + mirt_last_error(nullptr));
+        g_all.push_back(c);
+    }
+}
+
+const std::vector<MirtContext*>& IntersectionHIP::contexts() { return g_all; }
+
 void IntersectionHIP::shutdown() {
+    for (size_t k = 1; k < g_all.size(); k++) mirt_destroy(g_all[k]);
+    g_all.clear();
     if (g_ctx) mirt_destroy(g_ctx);
     g_ctx = nullptr;
     g_resident = nullptr;
@@ -45,11 +66,12 @@ MirtContext* IntersectionHIP::context() { return g_ctx; }
 void IntersectionHIP::loadKDTreeToDevice(const Scene& scene) {
     if (!g_ctx) throw std::runtime_error("IntersectionHIP::loadKDTreeToDevice: init() was not called");
     MirtSceneDesc d = scene.describe();
-    if (mirt_upload_scene(g_ctx, &d) != MIRT_OK) {
-        g_resident = nullptr;  // (a failed upload leaves no scene on the device)
-        g_resident_gen = 0;
-        throw std::runtime_error(std::string("IntersectionHIP::loadKDTreeToDevice: ") + mirt_last_error(g_ctx));
-    }
+    for (MirtContext* c : g_all)
+        if (mirt_upload_scene(c, &d) != MIRT_OK) {
+            g_resident = nullptr;  // (a failed upload leaves no scene on the device)
+            g_resident_gen = 0;
+            throw std::runtime_error(std::string("IntersectionHIP::loadKDTreeToDevice: ") + mirt_last_error(c));
+        }
     g_resident = &scene;
     g_resident_gen = scene.generation;
     g_resident_serial = mirt_scene_serial(g_ctx);
