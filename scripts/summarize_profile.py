@@ -42,9 +42,21 @@ for k in sorted(agg):
         print("    -> HBM-side read  : FETCH_SIZE %.1f KiB raw; x2 gfx950 correction for wide coalesced streams = %.3f MB" % (g("FETCH_SIZE"), 2 * g("FETCH_SIZE") * 1024 / 1e6))
     if g("WRITE_SIZE") is not None:
         print("    -> HBM-side write : WRITE_SIZE %.1f KiB = %.3f MB" % (g("WRITE_SIZE"), g("WRITE_SIZE") * 1024 / 1e6))
+    issue_frac = lanes = l2 = None
+    if g("SQ_INSTS_VALU") and g("GRBM_GUI_ACTIVE"):
+        # a wave64 VALU instruction occupies its SIMD (16 lanes) for 4 cycles; 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs
+        issue_frac = g("SQ_INSTS_VALU") * 4.0 / (1024.0 * g("GRBM_GUI_ACTIVE") / 8.0)
+        print("    -> VALU issue slots used: SQ_INSTS_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = %.3f" % issue_frac)
+    if g("SQ_INSTS_VALU") and g("SQ_THREAD_CYCLES_VALU"):
+        lanes = g("SQ_THREAD_CYCLES_VALU") / g("SQ_INSTS_VALU")
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and (g("TCC_HIT_sum") + g("TCC_MISS_sum")) > 0:
+        l2 = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
     if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
         traffic[k] = {"read_bytes": 2 * g("FETCH_SIZE") * 1024, "write_bytes": g("WRITE_SIZE") * 1024,
-                      "dispatches": calls[k]["FETCH_SIZE"]}
+                      "dispatches": calls[k]["FETCH_SIZE"],
+                      "valu_issue_frac": None if issue_frac is None else round(issue_frac, 4),
+                      "lanes_active_of_64": None if lanes is None else round(lanes, 2),
+                      "l2_hit_rate": None if l2 is None else round(l2, 4)}
 if len(sys.argv) > 2:
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of scripts/profile_gpu.sh; "
                          "FETCH_SIZE doubled (gfx950), mean per dispatch", "kernels": traffic},
