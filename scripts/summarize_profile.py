@@ -11,7 +11,7 @@ d = sys.argv[1]
 def short(name):
     name = re.sub(r"\(.*", "", name).replace("void ", "").replace("mirt::", "")
     return name[:70]
-print("# rocprofv3 summary of: python3 bench.py --steps N --warmup 1 --no-cpu --pt-spp 8 (scripts/profile_gpu.sh)")
+print("# rocprofv3 summary of: python3 bench.py --steps N --warmup 1 --no-cpu --pt-spp 8 [--workload X] (scripts/profile_gpu.sh), directory %s" % d)
 for f in sorted(glob.glob(os.path.join(d, "kt", "*", "*_kernel_stats.csv")))[-1:]:
     print("\n## kernel trace --stats (per kernel: calls, total ms, average us, % of GPU time)")
     for r in csv.DictReader(open(f)):
