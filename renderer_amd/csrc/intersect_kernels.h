@@ -73,6 +73,9 @@ constexpr uint32_t RAY_CHUNK_SMALL = MIRT_RAY_CHUNK;
 #ifndef MIRT_VOTE_NODE_WEIGHT
 #define MIRT_VOTE_NODE_WEIGHT 2
 #endif
+#ifndef MIRT_NODE_REPS
+#define MIRT_NODE_REPS 3  // traversal steps per node pass (lanes that reach a leaf sit the rest out)
+#endif
 #ifndef MIRT_VOTE_LEAF_WEIGHT
 #define MIRT_VOTE_LEAF_WEIGHT 1
 #endif
@@ -323,7 +326,9 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         if (n_node > 0 && n_node * MIRT_VOTE_NODE_WEIGHT >= n_leaf * MIRT_VOTE_LEAF_WEIGHT) {
             // ---- one traversal step for the lanes on an inner node ------------------------------------------
             if (COUNT && lane == 0) au.w_inner++;
-            if (want_node) {
+#pragma unroll
+            for (int rep = 0; rep < MIRT_NODE_REPS; rep++)
+            if (active && has && link >= 0) {
                 const PairRec P = pairs[link];
                 float lbl, lbr;
                 // conservative: only a proven miss is skipped (slab_miss_pair, mirt_dev.h)
