@@ -73,6 +73,9 @@ constexpr uint32_t RAY_CHUNK_SMALL = MIRT_RAY_CHUNK;
 #ifndef MIRT_VOTE_NODE_WEIGHT
 #define MIRT_VOTE_NODE_WEIGHT 2
 #endif
+#ifndef MIRT_LEAF_QUORUM
+#define MIRT_LEAF_QUORUM 2  // eighths of the leaf lanes that must still be scanning for another trip of a leaf pass
+#endif
 #ifndef MIRT_NODE_REPS
 #define MIRT_NODE_REPS 3  // traversal steps per node pass (lanes that reach a leaf sit the rest out)
 #endif
@@ -84,7 +87,7 @@ constexpr uint32_t RAY_CHUNK_SMALL = MIRT_RAY_CHUNK;
 #endif
 constexpr int FAST_AMBIGUOUS_BUDGET = MIRT_FAST_BUDGET;  // k_intersect<FAST>: unproven boxes a ray may enter before it is handed to the exact kernel
 #ifndef MIRT_LEAF_BATCH_FAST
-#define MIRT_LEAF_BATCH_FAST 4
+#define MIRT_LEAF_BATCH_FAST 6
 #endif
 // triangles a lane tests per leaf phase before the wave regroups (exact kernels / fast-tree kernels: swept separately)
 constexpr int LEAF_BATCH_EXACT = MIRT_LEAF_BATCH, LEAF_BATCH_FAST = MIRT_LEAF_BATCH_FAST;
@@ -371,38 +374,41 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         } else if (n_leaf > 0) {
             // ---- one leaf pass for the lanes on a leaf: up to LEAF_BATCH triangles; in NO_SELF mode a lane stops
             // at its first candidate and the predicate runs once for all such lanes together -----------------------
-            if (COUNT) {
-                int trips = want_leaf ? min(LEAF_BATCH, leaf_end - leaf_pos) : 0;
-                for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off));
-                if (lane == 0) {
-                    au.w_leaf += trips;
-                    au.w_outer++;
-                }
-            }
             int cand = -1;
             float cand_t = 0.f;
-            if (want_leaf) {
-                const int stop = min(leaf_pos + LEAF_BATCH, leaf_end);
+            {
+                // wave-level trips, one triangle per scanning lane and trip; the pass ends when every lane is through
+                // its share or, after the first trip, when fewer than MIRT_LEAF_QUORUM / 8 of the lanes that started are
+                // still scanning (the rest resume in the next leaf pass)
+                const int stop = want_leaf ? min(leaf_pos + LEAF_BATCH, leaf_end) : 0;
                 const int leaf_beg = (int)(~(uint32_t)link & 0xFFFFFFu);
-                int s = leaf_pos;
-                for (; s < stop; s++) {
-                    const TriRec T = sc.tris[s];
-                    if (COUNT) au.tri++;
-                    const float t = tri_test(T, o, d);
-                    if (!(t >= 0.f)) continue;
-                    if (ANYHIT && t - lim >= -1e-5f) continue;  // at or beyond the limit: no occluder
-                    if (!(best_slot < 0 || t < best || (t == best && best_slot < leaf_beg))) continue;
-                    if (MODE == MIRT_MODE_NO_SELF) {
-                        cand = s;
-                        cand_t = t;
-                        s++;
-                        break;
+                bool scanning = want_leaf && leaf_pos < stop;
+                for (int trip = 0; trip < LEAF_BATCH; trip++) {
+                    const int n_scan = (int)__popcll(__ballot(scanning));
+                    if (n_scan == 0 || (trip > 0 && n_scan * 8 < n_leaf * MIRT_LEAF_QUORUM)) break;
+                    if (COUNT && lane == 0) au.w_leaf++;
+                    if (scanning) {
+                        const int s = leaf_pos;
+                        const TriRec T = sc.tris[s];
+                        if (COUNT) au.tri++;
+                        const float t = tri_test(T, o, d);
+                        leaf_pos = s + 1;
+                        scanning = leaf_pos < stop;
+                        bool hit = t >= 0.f;
+                        if (ANYHIT && t - lim >= -1e-5f) hit = false;  // at or beyond the limit: no occluder
+                        if (hit && (best_slot < 0 || t < best || (t == best && best_slot < leaf_beg))) {
+                            if (MODE == MIRT_MODE_NO_SELF) {
+                                cand = s;
+                                cand_t = t;
+                                scanning = false;  // the predicate first
+                            } else if (!(MODE == MIRT_MODE_LAST_TID && __float_as_int(sc.vns[s].n1.w) == a)) {
+                                accept(t, s);
+                                if (ANYHIT && !has) scanning = false;
+                            }
+                        }
                     }
-                    if (MODE == MIRT_MODE_LAST_TID && __float_as_int(sc.vns[s].n1.w) == a) continue;
-                    accept(t, s);
-                    if (ANYHIT && !has) break;
                 }
-                leaf_pos = s;
+                if (COUNT && lane == 0) au.w_outer++;
             }
             if (MODE == MIRT_MODE_NO_SELF && cand >= 0) {
                 const VnRec V = sc.vns[cand];
