@@ -208,8 +208,9 @@ int mirt_intersect(MirtContext* ctx, const float* origins, const float* directio
                    const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out);
 /* Same with DEVICE pointers; asynchronous on `stream` (a hipStream_t, NULL = context stream). Two first-use
  * exceptions synchronise the stream once: a batch larger than any before (a list buffer grows), and, in modes
- * 0 / 1, the first batch of >= 2^18 rays on a scene (both traversal paths are run and timed, the faster one is
- * kept for that scene and mode; MIRT_FAST_ALL_MODES=0/1 in the environment fixes the choice instead).       */
+ * 0 / 1, the first batch of >= 2^18 rays on a scene: both traversal routes are run three times each, alternating, on
+ * (at most) the first 4 Mi rays of the batch and timed, and the one with the smaller median is kept for that scene and
+ * mode (the answers are the same either way; MIRT_FAST_ALL_MODES=0/1 in the environment fixes the choice instead).  */
 int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* directions,
                        const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
                        void* stream);

@@ -1216,14 +1216,17 @@ static int tune_routes(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, i
             T.use_fast = false;
             return route_exact<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, n, stride, t_out, id_out, nullptr, qwords);
         }
+    // timed on a prefix of the batch (the wavefront path tracer's camera pass can hold 10^8 rays); the whole batch
+    // then takes the route chosen
+    const uint32_t nt = std::min<uint32_t>(n, 1u << 22);
     HIPCHK(ctx, hipEventRecord(T.ev[0], st));
     for (int r = 0; r < REPS; r++) {
         HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
-        int rc = route_exact<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, n, stride, t_out, id_out, nullptr, qwords);
+        int rc = route_exact<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, nt, stride, t_out, id_out, nullptr, qwords);
         if (rc != MIRT_OK) return rc;
         HIPCHK(ctx, hipEventRecord(T.ev[2 * r + 1], st));
         HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
-        rc = route_fast<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, n, stride, t_out, id_out, nullptr, qwords);
+        rc = route_fast<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, nt, stride, t_out, id_out, nullptr, qwords);
         if (rc != MIRT_OK) return rc;
         HIPCHK(ctx, hipEventRecord(T.ev[2 * r + 2], st));
     }
@@ -1236,15 +1239,18 @@ static int tune_routes(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, i
     if (ok) {
         std::sort(ex, ex + REPS);
         std::sort(fa, fa + REPS);
-        T.exact_ns_per_ray = (double)ex[REPS / 2] * 1e6 / n;
-        T.fast_ns_per_ray = (double)fa[REPS / 2] * 1e6 / n;
+        T.exact_ns_per_ray = (double)ex[REPS / 2] * 1e6 / nt;
+        T.fast_ns_per_ray = (double)fa[REPS / 2] * 1e6 / nt;
         T.use_fast = fa[REPS / 2] < 0.97f * ex[REPS / 2];
         if (getenv("MIRT_DEBUG_TUNE"))
             fprintf(stderr, "[mirt] mode %d: reference tree %.3f ns/ray, fast tree %.3f ns/ray (medians of %d) -> %s\n", mode,
                     T.exact_ns_per_ray, T.fast_ns_per_ray, REPS, T.use_fast ? "fast tree" : "reference tree");
     }
     T.state = 3;
-    return MIRT_OK;
+    if (nt == n) return MIRT_OK;  // (the last timed run was the fast route over the whole batch)
+    HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
+    if (T.use_fast) return route_fast<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, n, stride, t_out, id_out, nullptr, qwords);
+    return route_exact<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, n, stride, t_out, id_out, nullptr, qwords);
 }
 
 // Closest hit of n rays (n_ptr != nullptr: the count is read on the device, at most n). `qwords`: three zeroed
