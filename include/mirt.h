@@ -169,7 +169,7 @@ typedef struct MirtRenderParams {
     MirtCamera camera;
     uint32_t spp_begin;      /* first global sample index rendered by this call              */
     uint32_t spp_count;      /* samples per pixel rendered by this call                      */
-    uint32_t max_depth;      /* MCRenderer::maxDepth (default 20, MCRenderer.h:106)          */
+    uint32_t max_depth;      /* MCRenderer::maxDepth (default 20, MCRenderer.h:106); <= 250  */
     uint32_t seed;           /* RNG stream = f(seed, pixel, global sample index, dimension)  */
     uint32_t spp_per_launch; /* samples per pixel kept in flight per wavefront; 0 = auto     */
 } MirtRenderParams;

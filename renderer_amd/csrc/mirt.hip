@@ -79,6 +79,10 @@ struct MirtContext {
     PathBuf pb[2]{};
     size_t pb_cap = 0;
     float* d_L = nullptr;
+    int l_gens = 1;              // radiance buffers in the L ring (wavefront chaining: up to 4)
+    PathBuf carry{};             // wavefront chaining: the paths a wavefront hands to the next one
+    size_t carry_cap = 0;
+    uint32_t* d_carry_cnt = nullptr;
     ShadowBuf shb{};             // PathTracerTest: shadow rays of the running bounce
     size_t shb_cap = 0;
     uint32_t* d_ns = nullptr;    // [cnt_cap] shadow rays written by bounce k
@@ -260,6 +264,16 @@ static void free_paths(MirtContext* ctx) {
     hipFree(ctx->d_L);
     ctx->d_L = nullptr;
     ctx->pb_cap = 0;
+    ctx->l_gens = 1;
+    {
+        PathBuf& p = ctx->carry;
+        hipFree(p.o); hipFree(p.d); hipFree(p.thr); hipFree(p.t); hipFree(p.slot);
+        hipFree(p.key); hipFree(p.ctr); hipFree(p.ids); hipFree(p.pid); hipFree(p.lpw);
+        p = PathBuf{};
+        ctx->carry_cap = 0;
+    }
+    hipFree(ctx->d_carry_cnt);
+    ctx->d_carry_cnt = nullptr;
     ShadowBuf& b = ctx->shb;
     hipFree(b.o); hipFree(b.d); hipFree(b.ids); hipFree(b.lim); hipFree(b.c); hipFree(b.pid); hipFree(b.vis);
     b = ShadowBuf{};
@@ -1599,25 +1613,42 @@ static int make_camera(MirtContext* ctx, const MirtCamera* c, DevCamera* out) {
     return MIRT_OK;
 }
 
-static int ensure_paths(MirtContext* ctx, size_t cap) {
-    if (cap <= ctx->pb_cap) return MIRT_OK;
+static int alloc_pathbuf(MirtContext* ctx, PathBuf& p, size_t cap) {
+    HIPCHK(ctx, hipMalloc(&p.o, 3 * cap * sizeof(float)));
+    HIPCHK(ctx, hipMalloc(&p.d, 3 * cap * sizeof(float)));
+    HIPCHK(ctx, hipMalloc(&p.thr, 3 * cap * sizeof(float)));
+    HIPCHK(ctx, hipMalloc(&p.t, cap * sizeof(float)));
+    HIPCHK(ctx, hipMalloc(&p.slot, cap * sizeof(int)));
+    HIPCHK(ctx, hipMalloc(&p.key, cap * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&p.ctr, cap * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&p.ids, cap * sizeof(int)));
+    HIPCHK(ctx, hipMalloc(&p.pid, cap * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&p.lpw, cap * sizeof(float)));
+    p.stride = (uint32_t)cap;
+    return MIRT_OK;
+}
+
+// path state for wavefronts of up to `cap` paths, `gens` radiance buffers in the L ring, and a carry buffer of
+// `carry_cap` paths (0: none)
+static int ensure_paths(MirtContext* ctx, size_t cap, int gens = 1, size_t carry_cap = 0) {
+    if (cap <= ctx->pb_cap && gens <= ctx->l_gens && carry_cap <= ctx->carry_cap) return MIRT_OK;
+    cap = std::max(cap, ctx->pb_cap);
+    gens = std::max(gens, ctx->l_gens);
+    carry_cap = std::max(carry_cap, ctx->carry_cap);
     free_paths(ctx);
     for (int k = 0; k < 2; k++) {
-        PathBuf& p = ctx->pb[k];
-        HIPCHK(ctx, hipMalloc(&p.o, 3 * cap * sizeof(float)));
-        HIPCHK(ctx, hipMalloc(&p.d, 3 * cap * sizeof(float)));
-        HIPCHK(ctx, hipMalloc(&p.thr, 3 * cap * sizeof(float)));
-        HIPCHK(ctx, hipMalloc(&p.t, cap * sizeof(float)));
-        HIPCHK(ctx, hipMalloc(&p.slot, cap * sizeof(int)));
-        HIPCHK(ctx, hipMalloc(&p.key, cap * sizeof(uint32_t)));
-        HIPCHK(ctx, hipMalloc(&p.ctr, cap * sizeof(uint32_t)));
-        HIPCHK(ctx, hipMalloc(&p.ids, cap * sizeof(int)));
-        HIPCHK(ctx, hipMalloc(&p.pid, cap * sizeof(uint32_t)));
-        HIPCHK(ctx, hipMalloc(&p.lpw, cap * sizeof(float)));
-        p.stride = (uint32_t)cap;
+        const int rc = alloc_pathbuf(ctx, ctx->pb[k], cap);
+        if (rc != MIRT_OK) return rc;
     }
-    HIPCHK(ctx, hipMalloc(&ctx->d_L, 3 * cap * sizeof(float)));
+    HIPCHK(ctx, hipMalloc(&ctx->d_L, (size_t)gens * 3 * cap * sizeof(float)));
+    if (carry_cap) {
+        const int rc = alloc_pathbuf(ctx, ctx->carry, carry_cap);
+        if (rc != MIRT_OK) return rc;
+        HIPCHK(ctx, hipMalloc(&ctx->d_carry_cnt, sizeof(uint32_t)));
+    }
     ctx->pb_cap = cap;
+    ctx->l_gens = gens;
+    ctx->carry_cap = carry_cap;
     return MIRT_OK;
 }
 
@@ -1657,6 +1688,26 @@ static hipEvent_t get_event(MirtContext* ctx, size_t k) {
     return ctx->events[k];
 }
 
+// per-bounce count / queue words of a wavefront (device) and their pinned host mirror
+static int ensure_counts(MirtContext* ctx, hipStream_t st, size_t words) {
+    if (words <= ctx->cnt_cap) return MIRT_OK;
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    hipFree(ctx->d_cnt);
+    hipFree(ctx->d_wq);
+    hipFree(ctx->d_ns);
+    hipFree(ctx->d_wq2);
+    hipHostFree(ctx->h_cnt);
+    ctx->d_cnt = ctx->d_wq = ctx->d_ns = ctx->d_wq2 = ctx->h_cnt = nullptr;
+    ctx->cnt_cap = 0;
+    HIPCHK(ctx, hipMalloc(&ctx->d_cnt, words * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->d_wq, 3 * words * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->d_ns, words * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->d_wq2, 3 * words * sizeof(uint32_t)));
+    HIPCHK(ctx, hipHostMalloc(&ctx->h_cnt, words * sizeof(uint32_t)));
+    ctx->cnt_cap = words;
+    return MIRT_OK;
+}
+
 // One wavefront of `S` samples per pixel starting at global sample index s0.
 // The live-path count of every bounce stays on the device (d_cnt[depth]); the host enqueues the
 // whole bounce sequence and looks at a count only now and then (to stop early) or when rays are
@@ -1671,27 +1722,15 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
     PathBuf* cur = &ctx->pb[0];
     PathBuf* nxt = &ctx->pb[1];
     const size_t words = (size_t)prm->max_depth + 4;
-    if (words > ctx->cnt_cap) {
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        hipFree(ctx->d_cnt);
-        hipFree(ctx->d_wq);
-        hipFree(ctx->d_ns);
-        hipFree(ctx->d_wq2);
-        hipHostFree(ctx->h_cnt);
-        ctx->d_cnt = ctx->d_wq = ctx->d_ns = ctx->d_wq2 = ctx->h_cnt = nullptr;
-        ctx->cnt_cap = 0;
-        HIPCHK(ctx, hipMalloc(&ctx->d_cnt, words * sizeof(uint32_t)));
-        HIPCHK(ctx, hipMalloc(&ctx->d_wq, 3 * words * sizeof(uint32_t)));
-        HIPCHK(ctx, hipMalloc(&ctx->d_ns, words * sizeof(uint32_t)));
-        HIPCHK(ctx, hipMalloc(&ctx->d_wq2, 3 * words * sizeof(uint32_t)));
-        HIPCHK(ctx, hipHostMalloc(&ctx->h_cnt, words * sizeof(uint32_t)));
-        ctx->cnt_cap = words;
+    {
+        const int rc = ensure_counts(ctx, st, words);
+        if (rc != MIRT_OK) return rc;
     }
     if (nee) {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_ns, 0, words * sizeof(uint32_t), st));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_wq2, 0, 3 * words * sizeof(uint32_t), st));
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_L, 0, 3 * ctx->pb_cap * sizeof(float), st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_L, 0, 3 * ctx->pb_cap * sizeof(float), st));  // (generation 0 of the L ring)
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt, 0, words * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_wq, 0, 3 * words * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_generate, dim3((P + B - 1) / B), dim3(B), 0, st, cam, P, s0, prm->seed, cur->o,
@@ -1721,7 +1760,7 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
             // k_connect add the unoccluded contributions before the next bounce touches L again
             uint32_t* n_sh = ctx->d_ns + depth;
             hipLaunchKernelGGL((k_shade<false, true>), dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur,
-                               n_in, bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, depth, prm->max_depth,
+                               n_in, bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth,
                                ctx->shb, n_sh);
             HIPCHK(ctx, hipGetLastError());
             int rcv = launch_visibility(ctx, st, MIRT_MODE_NO_SELF, ctx->shb.o, ctx->shb.d, ctx->shb.ids, ctx->shb.lim,
@@ -1731,10 +1770,10 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
                                (uint32_t)ctx->pb_cap);
         } else if (ctx->has_media)
             hipLaunchKernelGGL(k_shade<true>, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in,
-                               bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, depth, prm->max_depth);
+                               bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth);
         else
             hipLaunchKernelGGL(k_shade<false>, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in,
-                               bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, depth, prm->max_depth);
+                               bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth);
         HIPCHK(ctx, hipGetLastError());
         depths_run = depth + 1;
         if (depth == prm->max_depth) break;  // nothing survives the depth cap (MCRenderer.cpp:187-191)
@@ -1781,6 +1820,133 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
     return MIRT_OK;
 }
 
+// Wavefront chaining (plain path tracing, several wavefronts per call). A wavefront's last bounces hold a few
+// thousand paths each and cost ~0.18 ms apiece whatever their size (one ray's ~30 dependent traversal phases): 13 %
+// of a 32 Mi-path wavefront went into its last thirteen bounces. Here a wavefront is CUT after `cut` bounces: the
+// survivors, already intersected, move to a carry buffer and join the NEXT wavefront behind its camera hits, so every
+// launch of every wavefront but the last stays large. That works because k_shade reads each path's depth from the
+// path (top byte of its RNG counter word) and scores into the radiance buffer of the path's own wavefront (top bits
+// of its path id select one of `gens` buffers of the L ring); buffer g is added to the image, in wavefront order,
+// just before wavefront w + gens reuses it, when every path of wavefront w has ended (a path lives through at most
+// max_depth / cut + 1 wavefronts). Results are bit-identical to unchained wavefronts: same streams, same radiance
+// values, same order of accumulation. A cut whose survivors would not fit the carry buffer (a scene that absorbs
+// nothing) is skipped: that wavefront runs to its end.
+static uint32_t chain_cut(uint32_t max_depth) {
+    static const int forced = getenv("MIRT_CHAIN_CUT") ? atoi(getenv("MIRT_CHAIN_CUT")) : 0;  // experiments
+    if (forced > 0) return (uint32_t)forced;
+    // swept on the Cornell scene (32 Mi paths, Msamples/s): cut 6 1 293, 7 1 283, 8 1 275, 11 1 244 (unchained 1 187);
+    // the L ring holds max_depth / cut + 1 <= 4 buffers (two bits of the path id)
+    return std::max<uint32_t>(6u, max_depth / 4u + 1u);
+}
+
+static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderParams* prm, uint32_t S, float* rgb_sum,
+                       uint64_t* n_rays, size_t* ev_used, MirtRenderStats* stats) {
+    const uint32_t wh = (uint32_t)cam.width * (uint32_t)cam.height;
+    const uint32_t cut = chain_cut(prm->max_depth);
+    const int gens = (int)(prm->max_depth / cut) + 1;
+    const uint32_t n_wf = (prm->spp_count + S - 1) / S;
+    const size_t cap = ctx->pb_cap;  // (ensure_paths was called by render_common with the carry share included)
+    // this call's share of the carry buffer: a wavefront holds at most wh * S + carry_limit <= cap paths (the
+    // buffers themselves may be larger, left by an earlier call)
+    const size_t carry_limit = (size_t)wh * S / 4;
+    hipStream_t st = ctx->stream;
+    const int B = 256;
+    const size_t words = (size_t)prm->max_depth + 4;
+    int rc = ensure_counts(ctx, st, words);
+    if (rc != MIRT_OK) return rc;
+    auto samples_of = [&](uint32_t w) { return std::min(S, prm->spp_count - w * S); };
+    auto accumulate = [&](uint32_t w) -> int {  // wavefront w's radiance buffer into the image
+        hipLaunchKernelGGL(k_accumulate, dim3((wh + B - 1) / B), dim3(B), 0, st,
+                           (const float*)(ctx->d_L + (size_t)(w % gens) * 3 * cap), (uint32_t)cap, wh, samples_of(w), rgb_sum);
+        HIPCHK(ctx, hipGetLastError());
+        return MIRT_OK;
+    };
+    uint32_t carried = 0;  // host-side upper bound of the paths waiting in the carry buffer
+    for (uint32_t w = 0; w < n_wf; w++) {
+        const uint32_t s = samples_of(w), P = wh * s, g = w % (uint32_t)gens;
+        const bool last = w + 1 == n_wf;
+        PathBuf* cur = &ctx->pb[0];
+        PathBuf* nxt = &ctx->pb[1];
+        if (w >= (uint32_t)gens && (rc = accumulate(w - gens)) != MIRT_OK) return rc;  // its buffer is reused now
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_L + (size_t)g * 3 * cap, 0, 3 * cap * sizeof(float), st));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt, 0, words * sizeof(uint32_t), st));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_wq, 0, 3 * words * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_generate, dim3((P + B - 1) / B), dim3(B), 0, st, cam, P, prm->spp_begin + w * S, prm->seed, cur->o,
+                           cur->d, cur->stride, *cur, 1, g << PID_GEN_SHIFT);
+        HIPCHK(ctx, hipGetLastError());
+        auto timed_intersect = [&](int mode, PathBuf* pb, uint32_t n, const uint32_t* n_ptr, uint32_t* queue) -> int {
+            hipEvent_t e0 = get_event(ctx, *ev_used), e1 = get_event(ctx, *ev_used + 1);
+            if (!e0 || !e1) return fail(ctx, MIRT_E_HIP, "hipEventCreate failed");
+            *ev_used += 2;
+            HIPCHK(ctx, hipEventRecord(e0, st));
+            const int r = launch_intersect<false, true>(ctx, st, mode, pb->o, pb->d, pb->ids, n, pb->stride, pb->t, pb->slot,
+                                                        n_ptr, queue);
+            if (r != MIRT_OK) return r;
+            HIPCHK(ctx, hipEventRecord(e1, st));
+            return MIRT_OK;
+        };
+        rc = timed_intersect(MIRT_MODE_UNCONDITIONAL, cur, P, nullptr, ctx->d_wq);  // Camera.cpp:27-33: no predicate
+        if (rc != MIRT_OK) return rc;
+        if (carried) {  // the previous wavefront's survivors, already intersected, behind the camera hits
+            hipLaunchKernelGGL(k_carry, dim3((carried + B - 1) / B), dim3(B), 0, st, ctx->carry, (const uint32_t*)ctx->d_carry_cnt,
+                               carried, *cur, P, ctx->d_cnt, P);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        uint32_t bound = P + carried, depths_run = 0;
+        const bool counted_start = carried != 0;  // d_cnt[0] holds P + the carried count
+        carried = 0;
+        for (uint32_t it = 0; it <= prm->max_depth; it++) {
+            const uint32_t* n_in = (it || counted_start) ? ctx->d_cnt + it : nullptr;
+            uint32_t* n_out = ctx->d_cnt + it + 1;
+            if (ctx->has_media)
+                hipLaunchKernelGGL(k_shade<true>, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
+                                   n_out, ctx->d_L, (uint32_t)cap, prm->max_depth);
+            else
+                hipLaunchKernelGGL(k_shade<false>, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
+                                   n_out, ctx->d_L, (uint32_t)cap, prm->max_depth);
+            HIPCHK(ctx, hipGetLastError());
+            depths_run = it + 1;
+            if (it == prm->max_depth) break;  // (camera paths end here; carried ones ended earlier, by their own depth)
+            std::swap(cur, nxt);
+            const bool at_cut = !last && it + 1 == cut;
+            if (at_cut || (it >= 3 && ((it + 1) & it) == 0)) {  // look at the count: stop early / shrink grids / decide the cut
+                HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, n_out, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+                const uint32_t n = ctx->h_cnt[0];
+                if (n > bound) return fail(ctx, MIRT_E_HIP, "wavefront: live-path counter corrupted");
+                bound = n;
+                if (n == 0) break;
+            }
+            rc = timed_intersect(MIRT_MODE_NO_SELF, cur, bound, n_out, ctx->d_wq + 3 * (it + 1));  // MCRenderer.cpp:193-197
+            if (rc != MIRT_OK) return rc;
+            if (at_cut && bound <= carry_limit) {
+                hipLaunchKernelGGL(k_carry, dim3((bound + B - 1) / B), dim3(B), 0, st, *cur, (const uint32_t*)n_out, bound, ctx->carry, 0u,
+                                   ctx->d_carry_cnt, 0u);
+                HIPCHK(ctx, hipGetLastError());
+                carried = bound;
+                break;
+            }
+        }
+        // rays traced by this wavefront = P + the live counts of its bounces (read after the stream drains)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, (depths_run + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        *n_rays += P;
+        for (uint32_t k = 1; k < depths_run + 1 && k <= prm->max_depth; k++) *n_rays += ctx->h_cnt[k];
+        if (*ev_used > 4096) {  // fold the event pool so long renders do not grow it without bound
+            if (stats)
+                for (size_t k = 2; k + 1 < *ev_used; k += 2) {
+                    float ms = 0;
+                    hipEventElapsedTime(&ms, ctx->events[k], ctx->events[k + 1]);
+                    stats->intersect_ms += ms;
+                }
+            *ev_used = 2;
+        }
+    }
+    for (uint32_t w = n_wf > (uint32_t)gens ? n_wf - gens : 0; w < n_wf; w++)
+        if ((rc = accumulate(w)) != MIRT_OK) return rc;
+    return MIRT_OK;
+}
+
 static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* rgb_sum_dev, Capture* cap,
                          MirtRenderStats* stats, bool nee = false) {
     if (!ctx) return MIRT_E_INVALID;
@@ -1790,23 +1956,40 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
         return fail(ctx, MIRT_E_INVALID,
                     "render: the scene holds a homogeneous medium (MIRT_OBJ_VPM) whose own tree was not "
                     "uploaded (MirtSceneDesc.obj_trees)");
+    // a path carries its depth in the top byte of its RNG counter word (pt_kernels.h, CTR_DEPTH_SHIFT)
+    if (prm->max_depth > 250) return fail(ctx, MIRT_E_LIMIT, "render: max_depth above 250");
     DevCamera cam;
     int rc = make_camera(ctx, &prm->camera, &cam);
     if (rc != MIRT_OK) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint64_t wh = (uint64_t)cam.width * cam.height;
     uint32_t S = prm->spp_per_launch;
-    // ~128 Mi paths in flight (~18 GB of path state + L): each bounce is one launch, and the late
-    // bounces of a wavefront are latency-bound (a few thousand paths, ~0.2 ms each), so the wider the
-    // wavefront the smaller their share: 16 Mi -> 128 Mi paths is +25 % samples/s on the Cornell scene
-    if (S == 0) S = (uint32_t)std::max<uint64_t>(1, (1ull << 27) / wh);
+    // plain path tracing over several wavefronts: chained (run_chained); MIRT_CHAIN=0 switches it off (A/B)
+    static const bool chain_on = !getenv("MIRT_CHAIN") || atoi(getenv("MIRT_CHAIN")) != 0;
+    const bool can_chain = chain_on && !nee && !cap && rgb_sum_dev && chain_cut(prm->max_depth) < prm->max_depth &&
+                           prm->max_depth / chain_cut(prm->max_depth) + 1 <= 4;
+    // Each bounce is one launch and the late bounces of a wavefront are latency-bound (a few thousand
+    // paths, ~0.2 ms each), so an unchained wavefront wants to be wide: 16 Mi -> 128 Mi paths is +25 %
+    // samples/s on the Cornell scene, at ~18 GB of path state + L. A chained render has no such tail
+    // (the survivors of the cut ride along with the next wavefront), so its default is 32 Mi paths
+    // (~6 GB with the L ring and the carry buffer): 1305 Msamples/s against 1385 at 128 Mi.
+    if (S == 0) {
+        const uint64_t wide = std::max<uint64_t>(1, (1ull << 27) / wh), narrow = std::max<uint64_t>(1, (1ull << 25) / wh);
+        S = (uint32_t)(can_chain && prm->spp_count > narrow ? narrow : wide);
+    }
     S = std::min<uint32_t>(S, std::max<uint32_t>(prm->spp_count, 1));
     if (wh * S > (1ull << 30)) return fail(ctx, MIRT_E_LIMIT, "render: more than 2^30 paths per wavefront");
     if (nee && ctx->has_media)
         return fail(ctx, MIRT_E_INVALID, "render_pttest: scenes that hold a medium (MIRT_OBJ_VPM) are not supported "
                                          "by the light-connection integrator");
     if (nee) S = std::min<uint32_t>(S, (uint32_t)std::max<uint64_t>(1, (1ull << 26) / wh));
-    rc = ensure_paths(ctx, (size_t)(wh * S));
+    const bool chained = can_chain && prm->spp_count > S;
+    if (chained) {
+        const size_t carry_cap = (size_t)(wh * S) / 4;
+        rc = ensure_paths(ctx, (size_t)(wh * S) + carry_cap, (int)(prm->max_depth / chain_cut(prm->max_depth)) + 1, carry_cap);
+    } else {
+        rc = ensure_paths(ctx, (size_t)(wh * S));
+    }
     if (rc != MIRT_OK) return rc;
     if (nee) {
         rc = ensure_shadow(ctx, (size_t)(wh * S));
@@ -1818,6 +2001,10 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     size_t ev_used = 2;
     uint64_t n_rays = 0;
     HIPCHK(ctx, hipEventRecord(t0, ctx->stream));
+    if (chained) {
+        rc = run_chained(ctx, cam, prm, S, rgb_sum_dev, &n_rays, &ev_used, stats);
+        if (rc != MIRT_OK) return rc;
+    } else
     for (uint32_t done = 0; done < prm->spp_count; done += S) {
         uint32_t s = std::min(S, prm->spp_count - done);
         rc = run_wavefront(ctx, cam, prm, prm->spp_begin + done, s, rgb_sum_dev, cap, &n_rays, &ev_used, nee, &n_shadow);

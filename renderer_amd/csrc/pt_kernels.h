@@ -15,6 +15,14 @@
 
 namespace mirt {
 
+// Two fields of the path state carry a second value in their top bits (wavefront chaining, mirt.hip run_chained):
+//   ctr: bits 0..23 the RNG draw counter (a path draws < 200 numbers), bits 24..31 the path's DEPTH = scatter events
+//        behind it (k_shade reads it instead of a launch-wide depth: one launch may hold paths of different depths)
+//   pid: bits 0..29 the path index inside its wavefront (<= 2^30 paths), bits 30..31 which of the (up to four)
+//        radiance buffers of the L ring the path scores into
+constexpr uint32_t CTR_MASK = 0x00FFFFFFu, PID_MASK = 0x3FFFFFFFu;
+constexpr int CTR_DEPTH_SHIFT = 24, PID_GEN_SHIFT = 30;
+
 // SoA path state; planes have `stride` elements. Hit fields (t, slot) are filled by k_intersect.
 struct PathBuf {
     float* o;        // [3][stride] ray origin
@@ -92,7 +100,7 @@ __device__ __forceinline__ f3 camera_dir(const DevCamera& c, uint32_t pixel, flo
 // Camera ray batch. ray i: sample spp_begin + i / (W*H), pixel i % (W*H).
 __global__ void __launch_bounds__(256)
 k_generate(DevCamera cam, uint32_t n, uint32_t spp_begin, uint32_t seed, float* __restrict__ O,
-           float* __restrict__ D, uint32_t stride, PathBuf pb, int fill_state) {
+           float* __restrict__ D, uint32_t stride, PathBuf pb, int fill_state, uint32_t pid_gen = 0) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t wh = (uint32_t)cam.width * (uint32_t)cam.height;
@@ -136,7 +144,7 @@ k_generate(DevCamera cam, uint32_t n, uint32_t spp_begin, uint32_t seed, float* 
         pb.key[i] = key;
         pb.ctr[i] = ctr;
         pb.ids[i] = MIRT_PACK_IDS(-1, -1);
-        pb.pid[i] = (i / wh) * wh + pixel;  // sample_local * W*H + pixel, whatever the order of the batch
+        pb.pid[i] = ((i / wh) * wh + pixel) | pid_gen;  // sample_local * W*H + pixel, whatever the order of the batch
     }
 }
 
@@ -577,7 +585,7 @@ template <bool VOL, bool NEE = false>
 __global__ void __launch_bounds__(256)
 k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_in, uint32_t n_max,
         PathBuf out, uint32_t* __restrict__ n_out, float* __restrict__ L, uint32_t L_stride,
-        uint32_t depth, uint32_t max_depth, ShadowBuf sh = ShadowBuf{}, uint32_t* __restrict__ n_sh = nullptr) {
+        uint32_t max_depth, ShadowBuf sh = ShadowBuf{}, uint32_t* __restrict__ n_sh = nullptr) {
     __shared__ uint32_t s_wcnt[4];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_wcnt2[4];
@@ -621,8 +629,9 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
 
     bool alive = false;
     f3 no = mk3(0, 0, 0), nd = mk3(0, 0, 0), thr = mk3(0, 0, 0);
-    uint32_t key = 0, ctr = 0, pid = 0;
+    uint32_t key = 0, ctr = 0, pid = 0, depth = 0;
     int nids = 0;
+    float* Lg = L;  // the radiance buffer of this path's wavefront (L ring)
     bool shadow = false;  // NEE: this lane emits a shadow ray
     f3 sh_o = mk3(0, 0, 0), sh_d = mk3(0, 0, 0), sh_c = mk3(0, 0, 0);
     float sh_lim = 0.f, lpw = -1.f;
@@ -636,7 +645,10 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
             thr = load3(in.thr, in.stride, i);
             key = in.key[i];
             ctr = in.ctr[i];
+            depth = ctr >> CTR_DEPTH_SHIFT;  // scatter events behind this path (0: a camera ray's hit)
+            ctr &= CTR_MASK;
             pid = in.pid[i];
+            Lg = L + (size_t)(pid >> PID_GEN_SHIFT) * 3u * (size_t)L_stride;
             int inside = unpack_inside(in.ids[i]);
             if (VOL && depth == 0) inside = find_inside(sc, o, d, -1);  // Camera.cpp:35
             const TriRec T = sc.tris[slot];
@@ -748,9 +760,10 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                             mis = last / (last + dir_pdf_w);
                         }
                         const f3 add = (thr * mk3(ob.color[0], ob.color[1], ob.color[2])) * mis;
-                        L[pid] += add.x;
-                        L[L_stride + pid] += add.y;
-                        L[2 * L_stride + pid] += add.z;
+                        const uint32_t px = pid & PID_MASK;
+                        Lg[px] += add.x;
+                        Lg[L_stride + px] += add.y;
+                        Lg[2 * L_stride + px] += add.z;
                     } else {
                         if (sr.random) {  // PathTracerTest.cpp:59-63
                             f3 cdir, contrib;
@@ -799,11 +812,12 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
             thr = thr * div3(div3(sr.color, sr.dirProb), sr.originProb);
             nd = sr.nd;
             if (sr.emitted) {
-                float vd = vignette_div(cam, pid % ((uint32_t)cam.width * (uint32_t)cam.height));
+                const uint32_t px = pid & PID_MASK;
+                float vd = vignette_div(cam, px % ((uint32_t)cam.width * (uint32_t)cam.height));
                 f3 rad = div3(thr, vd);
-                L[pid] = rad.x;
-                L[L_stride + pid] = rad.y;
-                L[2 * L_stride + pid] = rad.z;
+                Lg[px] = rad.x;
+                Lg[L_stride + px] = rad.y;
+                Lg[2 * L_stride + px] = rad.z;
             } else if (!(len3(nd) < 0.5f)) {
                 // (MCRenderer.cpp:181 ends the path when length < 0.5: a NaN direction, e.g. from a bump-mapped
                 // triangle whose first edge runs along u (SceneObject.cpp:272 divides by duv1.y), is traced and misses)
@@ -875,7 +889,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
         store3(out.d, out.stride, j, nd);
         store3(out.thr, out.stride, j, thr);
         out.key[j] = key;
-        out.ctr[j] = ctr;
+        out.ctr[j] = ctr | ((depth + 1u) << CTR_DEPTH_SHIFT);
         out.ids[j] = nids;
         out.pid[j] = pid;
         if (NEE) out.lpw[j] = lpw;
@@ -890,7 +904,7 @@ k_connect(ShadowBuf sh, const uint32_t* __restrict__ n_ptr, uint32_t n_max, floa
     const uint32_t n = min(*n_ptr, n_max);
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n || !sh.vis[j]) return;
-    const uint32_t pid = sh.pid[j];
+    const uint32_t pid = sh.pid[j] & PID_MASK;
     L[pid] += sh.c[j];
     L[L_stride + pid] += sh.c[sh.stride + j];
     L[2 * L_stride + pid] += sh.c[2 * sh.stride + j];
@@ -912,6 +926,28 @@ k_accumulate(const float* __restrict__ L, uint32_t L_stride, uint32_t wh, uint32
     rgb_sum[3 * p] += r;
     rgb_sum[3 * p + 1] += g;
     rgb_sum[3 * p + 2] += b;
+}
+
+// Wavefront chaining (mirt.hip run_chained): moves the n = min(*n_src, n_max) intersected paths src[0, n) to
+// dst[dst_off, dst_off + n) and leaves cnt_base + n in *cnt_out: the survivors of a wavefront's cut into the carry
+// buffer, and from there behind the next wavefront's camera hits.
+__global__ void __launch_bounds__(256)
+k_carry(PathBuf src, const uint32_t* __restrict__ n_src, uint32_t n_max, PathBuf dst, uint32_t dst_off,
+        uint32_t* __restrict__ cnt_out, uint32_t cnt_base) {
+    const uint32_t n = min(*n_src, n_max);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *cnt_out = cnt_base + n;
+    if (i >= n) return;
+    const uint32_t j = dst_off + i;
+    store3(dst.o, dst.stride, j, load3(src.o, src.stride, i));
+    store3(dst.d, dst.stride, j, load3(src.d, src.stride, i));
+    store3(dst.thr, dst.stride, j, load3(src.thr, src.stride, i));
+    dst.t[j] = src.t[i];
+    dst.slot[j] = src.slot[i];
+    dst.key[j] = src.key[i];
+    dst.ctr[j] = src.ctr[i];
+    dst.ids[j] = src.ids[i];
+    dst.pid[j] = src.pid[i];
 }
 
 // a[i] += b[i]: the reduce step of mirt_render_pt_multi (context k's radiance sums into context 0's)

@@ -85,6 +85,54 @@ def test_determinism_sharding_and_batching(gpu, cornell, ra):
     assert not np.array_equal(a, d)
 
 
+def _chained_vs_separate(dev, cam, spp, spl, max_depth, seed=5):
+    """one call over several wavefronts (chained: run_chained in mirt.hip) against one call per wavefront
+    into the same accumulator (each a single, unchained wavefront): same bits, same ray count"""
+    import torch
+    a = torch.zeros(cam.height, cam.width, 3, device="cuda")
+    st = dev.render_pt_dev(cam, a.data_ptr(), spp, max_depth=max_depth, seed=seed, spp_per_launch=spl)
+    b = torch.zeros_like(a)
+    rays = 0
+    for begin in range(0, spp, spl):
+        s = dev.render_pt_dev(cam, b.data_ptr(), min(spl, spp - begin), spp_begin=begin, max_depth=max_depth,
+                              seed=seed, spp_per_launch=spl)
+        rays += int(s.n_rays)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b), (max_depth, spl, float((a - b).abs().max()))
+    assert int(st.n_rays) == rays and st.n_samples == cam.width * cam.height * spp
+    return a
+
+
+def test_chained_wavefronts_equal_separate_wavefronts(gpu, cornell, ra):
+    """Wavefront chaining: the survivors of a wavefront's cut finish inside the next wavefronts (per-path
+    depth, ring of radiance buffers). Depth caps that give 2, 3 and 4 ring buffers, a cap too small to
+    chain, a ragged last wavefront, and a scene that absorbs so little that the cut is skipped (its
+    survivors do not fit the carry buffer, a quarter of the wavefront)."""
+    import torch
+    gpu.upload(cornell.describe())
+    cam = cornell.camera()
+    for md, spl in ((20, 3), (7, 2), (6, 2), (40, 4), (100, 5), (250, 2)):
+        _chained_vs_separate(gpu, cam, 4 * spl + 1, spl, md)
+    with pytest.raises(ra.MirtError, match="max_depth"):
+        gpu.render_pt(cam, 1, max_depth=251)
+    m = meshgen.cornell_with_meshes(2)
+    for k in range(len(m["objects"])):
+        if m["objects"]["type"][k] != ra.OBJ_EMISSIVE:
+            m["objects"]["type"][k] = ra.OBJ_DIFFUSE
+            m["objects"]["color"][k] = (0.99, 0.99, 0.99)
+    s = ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"], m["objects"], m["tri_vn"])
+    gpu.upload(s.describe())
+    cam = ra.make_camera(96, 96, 65)
+    P = 96 * 96 * 4
+    o = torch.empty(3, P, device="cuda")
+    d = torch.empty(3, P, device="cuda")
+    aux = torch.empty(P, dtype=torch.int32, device="cuda")
+    alive = gpu.capture_rays_dev(cam, 4, 6, 6, o.data_ptr(), d.data_ptr(), aux.data_ptr(), P, seed=5)
+    assert alive > P // 4, alive  # (else this scene does not exercise the skipped cut)
+    _chained_vs_separate(gpu, cam, 14, 4, 20)
+    s.close()
+
+
 def test_depth_cap_and_edge_sizes(gpu, cornell, cornell_oracle, ra):
     gpu.upload(cornell.describe())
     cam = cornell.camera()
