@@ -50,6 +50,9 @@ namespace mirt {
 #ifndef MIRT_RAY_CHUNK_MIN_RAYS
 #define MIRT_RAY_CHUNK_MIN_RAYS (1u << 20)
 #endif
+#ifndef MIRT_TRI_KEEP
+#define MIRT_TRI_KEEP 0  // 1: a lane that stops at a triangle keeps the record in registers for the plane part
+#endif
 #ifndef MIRT_LEAF_BATCH
 #define MIRT_LEAF_BATCH 8
 #endif
@@ -70,8 +73,10 @@ constexpr uint32_t RAY_CHUNK_SMALL = MIRT_RAY_CHUNK;
 // a traversal step runs when (lanes on inner nodes) * NODE_WEIGHT >= (lanes on leaves) * LEAF_WEIGHT, else a leaf pass.
 // Swept on the 12.6 M-ray bounce batches (Cornell / 1 M triangles, ms): 1:1 3.45 / 5.62, 2:1 3.26 / 5.63, 3:1 3.31 / 5.90,
 // 4:1 3.36 / 6.14, 1:2 3.74 / 5.92 (leaf batch 3-4, refill at 16 idle lanes; the while-while form: 3.52 / 7.19).
+// Again with the triangle test split (edge signs per trip, plane part once per pass): 2:1 2.47 / 4.42, 3:2 2.45 / 4.30,
+// 1:1 2.49 / 4.29.
 #ifndef MIRT_VOTE_NODE_WEIGHT
-#define MIRT_VOTE_NODE_WEIGHT 2
+#define MIRT_VOTE_NODE_WEIGHT 3
 #endif
 #ifndef MIRT_LEAF_QUORUM
 #define MIRT_LEAF_QUORUM 2  // eighths of the leaf lanes that must still be scanning for another trip of a leaf pass
@@ -80,7 +85,7 @@ constexpr uint32_t RAY_CHUNK_SMALL = MIRT_RAY_CHUNK;
 #define MIRT_NODE_REPS 3  // traversal steps per node pass (lanes that reach a leaf sit the rest out)
 #endif
 #ifndef MIRT_VOTE_LEAF_WEIGHT
-#define MIRT_VOTE_LEAF_WEIGHT 1
+#define MIRT_VOTE_LEAF_WEIGHT 2
 #endif
 #ifndef MIRT_FAST_BUDGET
 #define MIRT_FAST_BUDGET 16
@@ -199,7 +204,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     pre.inv = mk3(0, 0, 0);
     pre.a_ray = 0.f;
     pre.fast = false;
-    RayPre2 pre2 = ray_pairs(o, pre);
+    RayPre2 pre2 = ray_pairs(o, d, pre);
 
     // does the box pass the reference test? Decided by the slab classifier when it can prove the
     // answer, by the reference arithmetic itself (box_test) otherwise: rarely taken, so whole waves
@@ -307,7 +312,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 has = false;
                 active = true;
                 pre = ray_prepare(sc, o, d);
-                pre2 = ray_pairs(o, pre);
+                pre2 = ray_pairs(o, d, pre);
                 float lb;
                 const int code = slab_classify(root_lo, root_hi, box_is_flat(root_lo, root_hi), o, pre, lb);
                 if (FAST) {
@@ -375,13 +380,14 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             // ---- one leaf pass for the lanes on a leaf: up to LEAF_BATCH triangles; in NO_SELF mode a lane stops
             // at its first candidate and the predicate runs once for all such lanes together -----------------------
             int cand = -1;
-            float cand_t = 0.f;
+            const int leaf_beg = (int)(~(uint32_t)link & 0xFFFFFFu);
+            TriRec T;
             {
-                // wave-level trips, one triangle per scanning lane and trip; the pass ends when every lane is through
-                // its share or, after the first trip, when fewer than MIRT_LEAF_QUORUM / 8 of the lanes that started are
+                // wave-level trips, one triangle per scanning lane and trip: the edge signs only (tri_inside); a lane
+                // whose line passes through a triangle stops there. The pass ends when every lane is through its
+                // share or, after the first trip, when fewer than MIRT_LEAF_QUORUM / 8 of the lanes that started are
                 // still scanning (the rest resume in the next leaf pass)
                 const int stop = want_leaf ? min(leaf_pos + LEAF_BATCH, leaf_end) : 0;
-                const int leaf_beg = (int)(~(uint32_t)link & 0xFFFFFFu);
                 bool scanning = want_leaf && leaf_pos < stop;
                 for (int trip = 0; trip < LEAF_BATCH; trip++) {
                     const int n_scan = (int)__popcll(__ballot(scanning));
@@ -389,33 +395,44 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                     if (COUNT && lane == 0) au.w_leaf++;
                     if (scanning) {
                         const int s = leaf_pos;
-                        const TriRec T = sc.tris[s];
+#if MIRT_TRI_KEEP
+                        T = sc.tris[s];  // (a lane that stops keeps its last record in registers for the plane part)
+#else
+                        T.x = sc.tris[s].x;
+                        T.y = sc.tris[s].y;
+                        T.z = sc.tris[s].z;
+#endif
                         if (COUNT) au.tri++;
-                        const float t = tri_test(T, o, d);
                         leaf_pos = s + 1;
                         scanning = leaf_pos < stop;
-                        bool hit = t >= 0.f;
-                        if (ANYHIT && t - lim >= -1e-5f) hit = false;  // at or beyond the limit: no occluder
-                        if (hit && (best_slot < 0 || t < best || (t == best && best_slot < leaf_beg))) {
-                            if (MODE == MIRT_MODE_NO_SELF) {
-                                cand = s;
-                                cand_t = t;
-                                scanning = false;  // the predicate first
-                            } else if (!(MODE == MIRT_MODE_LAST_TID && __float_as_int(sc.vns[s].n1.w) == a)) {
-                                accept(t, s);
-                                if (ANYHIT && !has) scanning = false;
-                            }
+                        if (tri_inside(T.x, T.y, T.z, pre2)) {
+                            cand = s;
+                            scanning = false;
                         }
                     }
                 }
                 if (COUNT && lane == 0) au.w_outer++;
             }
-            if (MODE == MIRT_MODE_NO_SELF && cand >= 0) {
-                const VnRec V = sc.vns[cand];
-                const f3 pos = o + d * cand_t;
-                const f3 nn = shading_normal<BUMP>(sc, sc.tris[cand], V, cand, pos);
-                if (legal_noself(dot3(d, nn), __float_as_int(V.n0.w), unpack_contact(a), unpack_inside(a)))
-                    accept(cand_t, cand);
+            // the distance (one division) and, in NO_SELF mode, the predicate: once per pass, for the lanes that stopped
+            if (cand >= 0) {
+#if !MIRT_TRI_KEEP
+                T = sc.tris[cand];
+#endif
+                const float t = tri_plane(T.n, tri_v2(T), o, d);
+                bool hit = t >= 0.f;
+                if (ANYHIT && t - lim >= -1e-5f) hit = false;  // at or beyond the limit: no occluder
+                hit = hit && (best_slot < 0 || t < best || (t == best && best_slot < leaf_beg));
+                if (MODE == MIRT_MODE_NO_SELF) {
+                    if (hit) {
+                        const VnRec V = sc.vns[cand];
+                        const f3 pos = o + d * t;
+                        const f3 nn = shading_normal<BUMP>(sc, T, V, cand, pos);
+                        if (legal_noself(dot3(d, nn), __float_as_int(V.n0.w), unpack_contact(a), unpack_inside(a)))
+                            accept(t, cand);
+                    }
+                } else if (hit && !(MODE == MIRT_MODE_LAST_TID && __float_as_int(sc.vns[cand].n1.w) == a)) {
+                    accept(t, cand);
+                }
             }
             if (want_leaf && has && leaf_pos >= leaf_end) pop();
         }
@@ -482,7 +499,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 has = false;
                 active = true;
                 pre = ray_prepare(sc, o, d);
-                pre2 = ray_pairs(o, pre);
+                pre2 = ray_pairs(o, d, pre);
                 float lb;
                 const int code = slab_classify(root_lo, root_hi, box_is_flat(root_lo, root_hi), o, pre, lb);
                 if (FAST) {

@@ -817,9 +817,8 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         h3 v0{p[0], p[1], p[2]}, v1{p[3], p[4], p[5]}, v2{p[6], p[7], p[8]};
         // KDTree.cpp:283-284: n = normalize(lines[0] x lines[1])
         h3 n = hnormalize(hcross(hsub(v1, v0), hsub(v2, v1)));
-        tris[k].a = make_float4(v0.x, v0.y, v0.z, n.x);
-        tris[k].b = make_float4(v1.x, v1.y, v1.z, n.y);
-        tris[k].c = make_float4(v2.x, v2.y, v2.z, n.z);
+        const float nn[3] = {n.x, n.y, n.z};
+        tris[k] = tri_pack(p, p + 3, p + 6, nn);
         float fo, fg;
         int ob = s->tri_obj[g];
         memcpy(&fo, &ob, 4);

@@ -39,12 +39,22 @@ __host__ __device__ __forceinline__ void pair_pack(const float4 lo, const float4
     *a = make_float4(lo.x, hi.x, lo.y, hi.y);
     *b = make_float4(lo.z, hi.z, lo.w, hi.w);
 }
-// triangle record in SLOT (leaf) order, 48 B: positions + the unit plane normal the reference
-// recomputes per test (KDTree.cpp:283-284), precomputed on the host with identical arithmetic.
-//   a = (v0, n.x)  b = (v1, n.y)  c = (v2, n.z)
+// triangle record in SLOT (leaf) order, 64 B (one per half cache line). Per axis one float4 that holds the
+// corner coordinates as the two register pairs the packed edge arithmetic of tri_inside() reads (edge 0 and
+// edge 1 side by side in v_pk_mul_f32 / v_pk_add_f32, no moves), then the unit plane normal the reference
+// recomputes per test (KDTree.cpp:283-284), precomputed on the host with identical arithmetic:
+//   x = (v0.x, v1.x, v1.x, v2.x)   y, z likewise   n = (n.x, n.y, n.z, 0)
 struct TriRec {
-    float4 a, b, c;
+    float4 x, y, z, n;
 };
+__host__ __device__ __forceinline__ TriRec tri_pack(const float v0[3], const float v1[3], const float v2[3], const float n[3]) {
+    TriRec T;
+    T.x = make_float4(v0[0], v1[0], v1[0], v2[0]);
+    T.y = make_float4(v0[1], v1[1], v1[1], v2[1]);
+    T.z = make_float4(v0[2], v1[2], v1[2], v2[2]);
+    T.n = make_float4(n[0], n[1], n[2], 0.f);
+    return T;
+}
 // per-slot shading data, 48 B, touched only for candidate hits that would win (predicate) and in
 // the shade kernel: corner normals (normal-matrix transformed, not normalised); for a triangle of an
 // object without vertex normals n0.xyz is its face normal normalize((v1-v0) x (v2-v0))
@@ -274,18 +284,55 @@ __device__ __forceinline__ int slab_classify(const float4 lo, const float4 hi, b
 // the same decision on a PairRec child (planes of one axis adjacent): identical operations and
 // roundings, two at a time
 typedef float v2f __attribute__((ext_vector_type(2)));
+// Packed fp32 with one half of a register pair broadcast to both result halves (VOP3P op_sel / op_sel_hi). Written
+// as instructions because this compiler does not fold a splat into op_sel: it builds the splat as a second register
+// pair (two moves and two more live registers per value, which at 7 waves per SIMD end up in scratch). Each is one
+// IEEE operation per half, rounded as the scalar instruction rounds (no contraction across them).
+//   pk_sub_b<H>(a, b) = a - b[H]     pk_mul_b<H>(a, b) = a * b[H]     pk_fma_b<HB, HC>(a, b, c) = fma(a, b[HB], c[HC])
+template <int H>
+__device__ __forceinline__ v2f pk_sub_b(v2f a, v2f b) {
+    v2f r;
+    if constexpr (H == 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int H>
+__device__ __forceinline__ v2f pk_mul_b(v2f a, v2f b) {
+    v2f r;
+    if constexpr (H == 0)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    else
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int HB, int HC>
+__device__ __forceinline__ v2f pk_fma_b(v2f a, v2f b, v2f c) {
+    v2f r;
+    if constexpr (HB == 0 && HC == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if constexpr (HB == 1 && HC == 1)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if constexpr (HB == 0 && HC == 1)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 struct RayPre2 {
     v2f oxy, ixy, ozi;  // origin / reciprocal direction as register pairs (halves broadcast by op_sel); ozi = (o.z, 1/d.z)
-    v2f cxy;            // slab_miss_pair: (-o.x / d.x, -o.y / d.y) as RN(-o * RN(1/d)), and cz likewise
-    float cz;
+    v2f cxy;            // slab_miss_pair: (-o.x / d.x, -o.y / d.y) as RN(-o * RN(1/d)), and dzc.y likewise for z
+    v2f dxy, dzc;       // tri_inside: the direction; dzc = (d.z, -o.z / d.z)
 };
-__device__ __forceinline__ RayPre2 ray_pairs(f3 o, const RayPre& p) {
+__device__ __forceinline__ RayPre2 ray_pairs(f3 o, f3 d, const RayPre& p) {
     RayPre2 q;
+    q.dxy = v2f{d.x, d.y};
     q.oxy = v2f{o.x, o.y};
     q.ixy = v2f{p.inv.x, p.inv.y};
     q.ozi = v2f{o.z, p.inv.z};
     q.cxy = v2f{-o.x * p.inv.x, -o.y * p.inv.y};
-    q.cz = -o.z * p.inv.z;
+    q.dzc = v2f{d.z, -o.z * p.inv.z};
     return q;
 }
 __device__ __forceinline__ int slab_classify_pair(const float4 a, const float4 b, const RayPre2& q,
@@ -323,9 +370,9 @@ __device__ __forceinline__ int slab_classify_pair(const float4 a, const float4 b
 // happening (a nearly axis-parallel direction makes M enormous) is given up and left to the exact kernel.
 __device__ __forceinline__ bool slab_miss_pair(const float4 a, const float4 b, const RayPre2& q, const RayPre& p,
                                                float& lb, bool& unproven) {
-    const v2f tx = __builtin_elementwise_fma(v2f{a.x, a.y}, q.ixy.xx, q.cxy.xx);
-    const v2f ty = __builtin_elementwise_fma(v2f{a.z, a.w}, q.ixy.yy, q.cxy.yy);
-    const v2f tz = __builtin_elementwise_fma(v2f{b.x, b.y}, q.ozi.yy, v2f{q.cz, q.cz});
+    const v2f tx = pk_fma_b<0, 0>(v2f{a.x, a.y}, q.ixy, q.cxy);
+    const v2f ty = pk_fma_b<1, 1>(v2f{a.z, a.w}, q.ixy, q.cxy);
+    const v2f tz = pk_fma_b<1, 1>(v2f{b.x, b.y}, q.ozi, q.dzc);
     const float tn = fmaxf(fminf(tx.x, tx.y), fmaxf(fminf(ty.x, ty.y), fminf(tz.x, tz.y)));
     const float tf = fminf(fmaxf(tx.x, tx.y), fminf(fmaxf(ty.x, ty.y), fmaxf(tz.x, tz.y)));
     const float M = __builtin_fmaf(1.9073486e-06f /*32 * 2^-24*/, fabsf(tn) + fabsf(tf), p.a_ray);
@@ -362,28 +409,54 @@ __device__ __forceinline__ bool prune(float lb, bool have, float best) {
     return have && lb > best * 1.0001f + 1e-5f;
 }
 
-// ---- triangle test (KDTree.cpp:267-289), returns dist or -1 -------------------------------------
-__device__ __forceinline__ float tri_test(const TriRec& T, f3 o, f3 d) {
-    f3 v0 = mk3(T.a.x, T.a.y, T.a.z), v1 = mk3(T.b.x, T.b.y, T.b.z), v2 = mk3(T.c.x, T.c.y, T.c.z);
-    f3 n = mk3(T.a.w, T.b.w, T.c.w);
-    f3 l0 = v1 - v0, l1 = v2 - v1, l2 = v0 - v2;
-    f3 r0 = v0 - o, r1 = v1 - o, r2 = v2 - o;
-    float s0 = dot3(d, cross3(l0, r0));
-    float s1 = dot3(d, cross3(l1, r1));
-    float s2 = dot3(d, cross3(l2, r2));
-    bool all_pos = (s0 >= 0.f) & (s1 >= 0.f) & (s2 >= 0.f);
-    bool all_neg = (s0 <= 0.f) & (s1 <= 0.f) & (s2 <= 0.f);
-    float orthoDist = dot3(n, r2);
-    float dd = dot3(n, d);
-    float q = orthoDist / dd;
-    if (dd == 0.f || q < 0.f || !(all_pos | all_neg)) return -1.f;
+// ---- triangle test (KDTree.cpp:267-289) ----------------------------------------------------------
+// In two parts, each the reference's operations in the reference's order (no contraction), so the pair is the
+// reference test bit for bit: tri_inside() is the three edge signs (the ray's line passes through the triangle),
+// tri_plane() the distance along the ray (one IEEE division) with the reference's rejections. The traversal
+// kernels run the first per triangle and the second once per leaf pass, for the triangle a lane stopped at.
+__device__ __forceinline__ f3 tri_v0(const TriRec& T) { return f3{T.x.x, T.y.x, T.z.x}; }
+__device__ __forceinline__ f3 tri_v1(const TriRec& T) { return f3{T.x.y, T.y.y, T.z.y}; }
+__device__ __forceinline__ f3 tri_v2(const TriRec& T) { return f3{T.x.w, T.y.w, T.z.w}; }
+// (origin and direction come as the register pairs of RayPre2: a half broadcast to both edges is an op_sel of the
+// packed instruction, where a pair built from one scalar would cost two moves and two more registers)
+__device__ __forceinline__ bool tri_inside(const float4 X, const float4 Y, const float4 Z, const RayPre2& q) {
+    // edges 0 and 1 in the two halves of packed registers: l = (v1 - v0 | v2 - v1), r = (v0 - o | v1 - o)
+    const v2f ax = {X.x, X.y}, bx = {X.z, X.w}, ay = {Y.x, Y.y}, by = {Y.z, Y.w}, az = {Z.x, Z.y}, bz = {Z.z, Z.w};
+    const v2f lx = bx - ax, ly = by - ay, lz = bz - az;
+    const v2f rx = pk_sub_b<0>(ax, q.oxy), ry = pk_sub_b<1>(ay, q.oxy), rz = pk_sub_b<0>(az, q.ozi);
+    const v2f cx = ly * rz - lz * ry, cy = lz * rx - lx * rz, cz = lx * ry - ly * rx;  // cross3(l, r)
+    v2f s01 = pk_mul_b<0>(cx, q.dxy);                                                 // dot3(d, .)
+    s01 = s01 + pk_mul_b<1>(cy, q.dxy);
+    s01 = s01 + pk_mul_b<0>(cz, q.dzc);
+    const f3 o = mk3(q.oxy.x, q.oxy.y, q.ozi.x), d = mk3(q.dxy.x, q.dxy.y, q.dzc.x);
+    const f3 v0 = mk3(X.x, Y.x, Z.x), v2 = mk3(X.w, Y.w, Z.w);
+    const float s2 = dot3(d, cross3(v0 - v2, v2 - o));
+    const bool all_pos = (s01.x >= 0.f) & (s01.y >= 0.f) & (s2 >= 0.f);
+    const bool all_neg = (s01.x <= 0.f) & (s01.y <= 0.f) & (s2 <= 0.f);
+    return all_pos | all_neg;
+}
+__device__ __forceinline__ float tri_plane(const float4 N, f3 v2, f3 o, f3 d) {
+    const f3 n = mk3(N.x, N.y, N.z);
+    const float orthoDist = dot3(n, v2 - o);
+    const float dd = dot3(n, d);
+    const float q = orthoDist / dd;
+    if (dd == 0.f || q < 0.f) return -1.f;
     return q;
+}
+__device__ __forceinline__ float tri_test(const TriRec& T, f3 o, f3 d) {
+    RayPre2 q2;
+    q2.oxy = v2f{o.x, o.y};
+    q2.ozi = v2f{o.z, 0.f};
+    q2.dxy = v2f{d.x, d.y};
+    q2.dzc = v2f{d.z, 0.f};
+    const float q = tri_plane(T.n, tri_v2(T), o, d);  // (NaN stays NaN, as in the reference's single expression)
+    return tri_inside(T.x, T.y, T.z, q2) ? q : -1.f;
 }
 
 // ---- shading normal (SimpleShape.cpp:300-339 through SceneObject.cpp:250-254) ------------------
 __device__ __forceinline__ f3 world_normal(const TriRec& T, const VnRec& V, bool has_vn, f3 pos) {
     if (!has_vn) return mk3(V.n0.x, V.n0.y, V.n0.z);  // normalize((v1-v0) x (v2-v0)), rounded on the host at upload
-    f3 v0 = mk3(T.a.x, T.a.y, T.a.z), v1 = mk3(T.b.x, T.b.y, T.b.z), v2 = mk3(T.c.x, T.c.y, T.c.z);
+    f3 v0 = tri_v0(T), v1 = tri_v1(T), v2 = tri_v2(T);
     f3 b1 = v1 - v0, b2 = v2 - v0;
     f3 v = pos - v0;
     float d12 = dot3(b1, b2);
@@ -403,7 +476,7 @@ __device__ __forceinline__ f3 world_normal(const TriRec& T, const VnRec& V, bool
 __device__ __forceinline__ f3 tex_coord(const DevScene& sc, const TriRec& T, int slot, f3 pos) {
     if (!sc.vts) return mk3(0, 0, 0);
     const VtRec W = sc.vts[slot];
-    f3 v0 = mk3(T.a.x, T.a.y, T.a.z), v1 = mk3(T.b.x, T.b.y, T.b.z), v2 = mk3(T.c.x, T.c.y, T.c.z);
+    f3 v0 = tri_v0(T), v1 = tri_v1(T), v2 = tri_v2(T);
     f3 b1 = v1 - v0, b2 = v2 - v0;
     f3 v = pos - v0;
     float d12 = dot3(b1, b2);
@@ -505,7 +578,7 @@ __device__ __forceinline__ f3 rot_about(f3 axis, float angle, f3 v) {
 __device__ __forceinline__ f3 bump_normal(const DevScene& sc, const TriRec& T, int slot, const DevBump& B, f3 n, f3 pos) {
     const VtRec W = sc.vts[slot];
     const f3 g = tex_grad(sc.textures[B.texture], B.inv, tex_coord(sc, T, slot, pos));
-    f3 b1 = mk3(T.b.x, T.b.y, T.b.z) - mk3(T.a.x, T.a.y, T.a.z), b2 = mk3(T.c.x, T.c.y, T.c.z) - mk3(T.a.x, T.a.y, T.a.z);
+    f3 b1 = tri_v1(T) - tri_v0(T), b2 = tri_v2(T) - tri_v0(T);
     const f3 duv1 = mk3(W.t1.x, W.t1.y, W.t1.z) - mk3(W.t0.x, W.t0.y, W.t0.z);
     const f3 duv2 = mk3(W.t2.x, W.t2.y, W.t2.z) - mk3(W.t0.x, W.t0.y, W.t0.z);
     const float k2 = (g.x * duv1.y - g.y * duv1.x) / (duv1.y * duv2.x - duv1.x * duv2.y);

@@ -516,8 +516,7 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
     const float u1 = rng_float(ck, cc), u2 = rng_float(ck, cc);
     const float su1 = sqrtf(u1);
     const float u = 1.f - su1, v = u2 * su1;
-    const f3 y = (mk3(LT.a.x, LT.a.y, LT.a.z) * u + mk3(LT.b.x, LT.b.y, LT.b.z) * v) +
-                 mk3(LT.c.x, LT.c.y, LT.c.z) * ((1.f - u) - v);
+    const f3 y = (tri_v0(LT) * u + tri_v1(LT) * v) + tri_v2(LT) * ((1.f - u) - v);
     const DevObject lob = sc.objects[Lg.object];
     f3 ldir = pos - y;  // lightRay.direction = ray.origin - lightRay.origin
     const float dist = len3(ldir);
