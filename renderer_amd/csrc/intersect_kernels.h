@@ -426,8 +426,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                     if (hit) {
                         const VnRec V = sc.vns[cand];
                         const f3 pos = o + d * t;
-                        const f3 nn = shading_normal<BUMP>(sc, T, V, cand, pos);
-                        if (legal_noself(dot3(d, nn), __float_as_int(V.n0.w), unpack_contact(a), unpack_inside(a)))
+                        const float dn = noself_dn<BUMP>(sc, T, V, cand, pos, d);
+                        if (legal_noself(dn, __float_as_int(V.n0.w), unpack_contact(a), unpack_inside(a)))
                             accept(t, cand);
                     }
                 } else if (hit && !(MODE == MIRT_MODE_LAST_TID && __float_as_int(sc.vns[cand].n1.w) == a)) {
@@ -609,8 +609,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 if (cand >= 0) {
                     const VnRec V = sc.vns[cand];
                     const f3 pos = o + d * cand_t;
-                    const f3 nn = shading_normal<BUMP>(sc, sc.tris[cand], V, cand, pos);
-                    if (legal_noself(dot3(d, nn), __float_as_int(V.n0.w), unpack_contact(a), unpack_inside(a)))
+                    const float dn = noself_dn<BUMP>(sc, sc.tris[cand], V, cand, pos, d);
+                    if (legal_noself(dn, __float_as_int(V.n0.w), unpack_contact(a), unpack_inside(a)))
                         accept(cand_t, cand);
                 }
                 more = active && has && leaf_pos < stop;

@@ -833,6 +833,10 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         const int flags = hv | (obj_bump[ob] << 8);  // shading_normal (mirt_dev.h)
         memcpy(&fh, &flags, 4);
         vns[k].n2 = make_float4(vn ? vn[6] : 0.f, vn ? vn[7] : 0.f, vn ? vn[8] : 0.f, fh);
+        // the triangle-only terms of the barycentric weights (world_normal_raw, mirt_dev.h; SimpleShape.cpp:300-339)
+        const h3 b1 = hsub(v1, v0), b2 = hsub(v2, v0);
+        const float d12 = hdot(b1, b2), l1 = sqrtf(hdot(b1, b1)), l2 = sqrtf(hdot(b2, b2));
+        vns[k].w = make_float4(l1, d12, d12 * d12 - l1 * l1 * l2 * l2, l1 * l1);
     };
     const std::vector<int> main_src = seam_order(main_tree);  // device slot -> position in the reference's slot order
     for (int k = 0; k < T; k++) fill_slot((size_t)k, s->slot_tid[main_src[k]]);

@@ -55,12 +55,16 @@ __host__ __device__ __forceinline__ TriRec tri_pack(const float v0[3], const flo
     T.n = make_float4(n[0], n[1], n[2], 0.f);
     return T;
 }
-// per-slot shading data, 48 B, touched only for candidate hits that would win (predicate) and in
+// per-slot shading data, 64 B, touched only for candidate hits that would win (predicate) and in
 // the shade kernel: corner normals (normal-matrix transformed, not normalised); for a triangle of an
 // object without vertex normals n0.xyz is its face normal normalize((v1-v0) x (v2-v0))
 // (SimpleShape.cpp:300-339), rounded on the host exactly as the reference rounds it per query.
+// w: the terms of the reference's barycentric weights that depend on the triangle alone, computed on the host
+// with the reference's operations in the reference's order (world_normal): with b1 = v1 - v0, b2 = v2 - v0,
+//   w = (l1 = |b1|, d12 = b1 . b2, d12 * d12 - l1 * l1 * l2 * l2, l1 * l1)
 struct VnRec {
     float4 n0, n1, n2;  // .w: n0 bits(object id), n1 bits(global tid), n2 bits(object has vertex normals)
+    float4 w;
 };
 
 // corner texture coordinates of one slot (SimpleShape::vertexTexCoordList through the face's indices)
@@ -320,6 +324,30 @@ __device__ __forceinline__ v2f pk_fma_b(v2f a, v2f b, v2f c) {
         asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// min / max of values that come out of the instructions above: written as instructions too, because the compiler
+// puts a canonicalising v_max_f32 x, x in front of every fminf / fmaxf whose operand it cannot prove canonical
+// (twelve per traversal step). No NaN reaches them: rays with a zero or denormal direction component are outside
+// the classifier's error model (RayPre::fast) and never enter the fast kernels' traversal.
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 struct RayPre2 {
     v2f oxy, ixy, ozi;  // origin / reciprocal direction as register pairs (halves broadcast by op_sel); ozi = (o.z, 1/d.z)
     v2f cxy;            // slab_miss_pair: (-o.x / d.x, -o.y / d.y) as RN(-o * RN(1/d)), and dzc.y likewise for z
@@ -373,12 +401,12 @@ __device__ __forceinline__ bool slab_miss_pair(const float4 a, const float4 b, c
     const v2f tx = pk_fma_b<0, 0>(v2f{a.x, a.y}, q.ixy, q.cxy);
     const v2f ty = pk_fma_b<1, 1>(v2f{a.z, a.w}, q.ixy, q.cxy);
     const v2f tz = pk_fma_b<1, 1>(v2f{b.x, b.y}, q.ozi, q.dzc);
-    const float tn = fmaxf(fminf(tx.x, tx.y), fmaxf(fminf(ty.x, ty.y), fminf(tz.x, tz.y)));
-    const float tf = fminf(fmaxf(tx.x, tx.y), fminf(fmaxf(ty.x, ty.y), fmaxf(tz.x, tz.y)));
+    const float tn = vmax3(vmin(tx.x, tx.y), vmin(ty.x, ty.y), vmin(tz.x, tz.y));
+    const float tf = vmin3(vmax(tx.x, tx.y), vmax(ty.x, ty.y), vmax(tz.x, tz.y));
     const float M = __builtin_fmaf(1.9073486e-06f /*32 * 2^-24*/, fabsf(tn) + fabsf(tf), p.a_ray);
     const float gap = tf - tn;
-    lb = fmaxf(tn, 0.f);
-    const bool miss = (tf < -M) | (gap < -M);
+    lb = vmax(tn, 0.f);
+    const bool miss = vmin(tf, gap) < -M;  // (tf < -M) | (gap < -M)
     unproven = !miss & (__float_as_int(b.w) == 0) & !(gap > M);
     return miss;
 }
@@ -454,20 +482,22 @@ __device__ __forceinline__ float tri_test(const TriRec& T, f3 o, f3 d) {
 }
 
 // ---- shading normal (SimpleShape.cpp:300-339 through SceneObject.cpp:250-254) ------------------
-__device__ __forceinline__ f3 world_normal(const TriRec& T, const VnRec& V, bool has_vn, f3 pos) {
-    if (!has_vn) return mk3(V.n0.x, V.n0.y, V.n0.z);  // normalize((v1-v0) x (v2-v0)), rounded on the host at upload
+// the interpolated corner normals before normalisation
+__device__ __forceinline__ f3 world_normal_raw(const TriRec& T, const VnRec& V, f3 pos) {
     f3 v0 = tri_v0(T), v1 = tri_v1(T), v2 = tri_v2(T);
     f3 b1 = v1 - v0, b2 = v2 - v0;
     f3 v = pos - v0;
-    float d12 = dot3(b1, b2);
-    float l1 = len3(b1), l2 = len3(b2);
+    const float l1 = V.w.x, d12 = V.w.y, den = V.w.z, l1l1 = V.w.w;
     float vb1 = dot3(v, b1), vb2 = dot3(v, b2);
-    float u2 = (vb1 * d12 - vb2 * l1 * l1) / (d12 * d12 - l1 * l1 * l2 * l2);
-    float u1 = (vb1 - u2 * d12) / (l1 * l1);
+    float u2 = (vb1 * d12 - vb2 * l1 * l1) / den;
+    float u1 = (vb1 - u2 * d12) / l1l1;
     f3 n0 = mk3(V.n0.x, V.n0.y, V.n0.z), n1 = mk3(V.n1.x, V.n1.y, V.n1.z),
        n2 = mk3(V.n2.x, V.n2.y, V.n2.z);
-    f3 nn = ((1.f - u1 - u2) * n0 + u1 * n1) + u2 * n2;
-    return normalize3(nn);
+    return ((1.f - u1 - u2) * n0 + u1 * n1) + u2 * n2;
+}
+__device__ __forceinline__ f3 world_normal(const TriRec& T, const VnRec& V, bool has_vn, f3 pos) {
+    if (!has_vn) return mk3(V.n0.x, V.n0.y, V.n0.z);  // normalize((v1-v0) x (v2-v0)), rounded on the host at upload
+    return normalize3(world_normal_raw(T, V, pos));
 }
 
 // ---- textures (Texture.cpp:43-94, SimpleShape.cpp:274-298) --------------------------------------
@@ -601,6 +631,23 @@ __device__ __forceinline__ f3 shading_normal(const DevScene& sc, const TriRec& T
     f3 n = world_normal(T, V, (flags & 1) != 0, pos);
     if (BUMP && (flags >> 8) != 0) n = bump_normal(sc, T, slot, sc.bumps[(flags >> 8) - 1], n, pos);
     return n;
+}
+
+// d . shading normal as the predicate needs it: only its SIGN (and whether it is zero) enters legal_noself. For a
+// smooth triangle the reference normalises the interpolated normal nn first (a square root and three divisions);
+// with S = sum d_a nn_a, the reference's value is S / |nn| up to 4u sum |d_a nn_a| / |nn| (u = 2^-24: one rounding
+// per normalised component, product and sum) and the value computed here from nn itself is S up to 3u of the same
+// sum, so when it exceeds 16u of that sum in magnitude its sign IS the reference's; otherwise (one candidate in
+// ~10^6; NaN and underflow land here too) the reference's own operations run.
+template <bool BUMP>
+__device__ __forceinline__ float noself_dn(const DevScene& sc, const TriRec& T, const VnRec& V, int slot, f3 pos, f3 d) {
+    const int flags = __float_as_int(V.n2.w);
+    if ((flags & 1) == 0 || (BUMP && (flags >> 8) != 0)) return dot3(d, shading_normal<BUMP>(sc, T, V, slot, pos));
+    const f3 nn = world_normal_raw(T, V, pos);
+    float dn = dot3(d, nn);
+    const float mag = (fabsf(d.x * nn.x) + fabsf(d.y * nn.y)) + fabsf(d.z * nn.z);
+    if (!(fabsf(dn) > 9.5367431640625e-07f /*16 * 2^-24*/ * mag)) dn = dot3(d, normalize3(nn));
+    return dn;
 }
 
 // NoSelfIntersectionCondition.cpp:12-27; ids are object ids, -1 = NULL
