@@ -242,11 +242,11 @@ int mirt_visibility(MirtContext* ctx, const float* origins, const float* directi
 int mirt_visibility_dev(MirtContext* ctx, const float* origins, const float* directions, const int32_t* aux,
                         const float* max_dist, size_t n, int mode, uint8_t* visible, void* stream);
 /* The fast tree mirt_upload_scene builds for the predicate mode (no counterpart in the reference): a
- * binned surface-area hierarchy over the LEAVES of the scene tree (their slot ranges and boxes unchanged),
- * in the same pre-order layout as MirtSceneDesc (left child = i + 1; node_right < 0 marks a leaf whose
- * [leaf_begin, leaf_end) is a slot range of the scene tree). Host-only, needs no GPU: for tools and tests.
- * Returns MIRT_E_LIMIT (with *n_nodes_out set) when capacity_nodes is too small; it never exceeds
- * scene->n_nodes.                                                                                  */
+ * binned surface-area hierarchy over the TRIANGLES of the scene tree, every leaf one triangle with the box
+ * of its corners, in the same pre-order layout as MirtSceneDesc (left child = i + 1; node_right < 0 marks
+ * a leaf, whose [leaf_begin, leaf_begin + 1) is the triangle's slot in the scene tree's slot order).
+ * Host-only, needs no GPU: for tools and tests. Needs tri_pos and slot_tid of the descriptor. Returns
+ * MIRT_E_LIMIT (with *n_nodes_out set) when capacity_nodes is too small; 2 * n_tris - 1 nodes at most.  */
 int mirt_fast_tree(const MirtSceneDesc* scene, int32_t capacity_nodes, int32_t* n_nodes_out, float* node_min,
                    float* node_max, int32_t* node_right, int32_t* leaf_begin, int32_t* leaf_end);
 /* Instrumented run (never timed): same results plus the number of node-box tests and

@@ -641,7 +641,8 @@ float orderedIntersect(const OrcScene& S, const KRay& ray, const Condition& cond
 }
 
 // ---- the product's FAST path, restated (DESIGN.md "fast tree"): near-first pruned traversal of a tree
-// GIVEN by the caller whose leaves carry slot ranges of this scene's reference tree, entering every box a
+// GIVEN by the caller whose leaves carry slots of this scene's reference tree (single triangles, or any ranges
+// that lie inside one reference leaf), entering every box a
 // generously inflated slab test cannot exclude; then the winner's chain of reference boxes (leaf up to the
 // root) is checked with the reference box test, and a ray whose chain fails is answered by the exact
 // ordered traversal of the reference tree instead. Counts every box / triangle test on the way.
@@ -697,7 +698,10 @@ float fastIntersect(const OrcScene& S, const GivenTree& T, const std::vector<int
                 unsigned tid = (unsigned)S.slotTid[s];
                 float t = triIntersect(S, ray, tid, nullptr);
                 if (!(t >= 0)) continue;
-                bool wins = bestSlot < 0 || t < best || (t == best && bestSlot < lb);
+                // ties follow the reference's order whatever the given tree's leaves are: between reference leaves
+                // the later one wins (KDTree.cpp:319-320), inside one the earlier triangle (KDTree.cpp:305)
+                auto rank = [&](int q) { return S.fbegin[slotNode[q]] + (S.fend[slotNode[q]] - 1 - q); };
+                bool wins = bestSlot < 0 || t < best || (t == best && rank(s) > rank(bestSlot));
                 if (wins && cond.legal(S, ray, tid, t)) {
                     best = t;
                     bestSlot = s;

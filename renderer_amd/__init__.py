@@ -265,8 +265,8 @@ class HostScene:
         return out
 
     def fast_tree(self):
-        """mirt_fast_tree: the surface-area hierarchy over this scene's leaves (host only)."""
-        N = self.n_nodes
+        """mirt_fast_tree: the surface-area hierarchy over this scene's triangles (host only)."""
+        N = max(1, 2 * self.n_tris)
         out = dict(node_min=np.empty((N, 3), np.float32), node_max=np.empty((N, 3), np.float32),
                    node_right=np.empty(N, np.int32), leaf_begin=np.empty(N, np.int32), leaf_end=np.empty(N, np.int32))
         n = C.c_int32()

@@ -81,6 +81,9 @@ constexpr uint32_t RAY_CHUNK_SMALL = MIRT_RAY_CHUNK;
 #ifndef MIRT_LEAF_QUORUM
 #define MIRT_LEAF_QUORUM 2  // eighths of the leaf lanes that must still be scanning for another trip of a leaf pass
 #endif
+#ifndef MIRT_LEAF_REPS
+#define MIRT_LEAF_REPS 2  // triangles per leaf pass (a lane goes on when its next node is a leaf again)
+#endif
 #ifndef MIRT_NODE_REPS
 #define MIRT_NODE_REPS 3  // traversal steps per node pass (lanes that reach a leaf sit the rest out)
 #endif
@@ -177,10 +180,17 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     typedef __attribute__((address_space(1))) unsigned long long glb_u64;
     lds_u64* stk = (lds_u64*)lds + threadIdx.x;
-    glb_u64* stk_deep = (glb_u64*)spill + ((size_t)blockIdx.x * bs + threadIdx.x);
+    // (the deep levels' address is put together where it is used, rarely: two more VGPRs saved)
     const size_t deep_stride = (size_t)gridDim.x * bs;
-    const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    auto stk_deep = [&](uint32_t level) -> glb_u64* {
+        return (glb_u64*)spill + ((size_t)blockIdx.x * bs + threadIdx.x) + (size_t)level * deep_stride;
+    };
+    // (the lane index and a lane's rank inside a ballot come from v_mbcnt where they are needed: kept in registers
+    // they cost three VGPRs of a budget of 72 at 7 waves per SIMD)
+    auto lane_id = [&]() -> uint32_t { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); };
+    auto rank_in = [&](unsigned long long m) -> uint32_t {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
     const float INF = __builtin_inff();
 
     Audit au;
@@ -240,7 +250,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             if ((uint32_t)sp < lds_levels)
                 packed = stk[sp * bs];
             else
-                packed = stk_deep[(sp - lds_levels) * deep_stride];
+                packed = *stk_deep(sp - lds_levels);
             const uint2 e = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
             if (__uint_as_float(e.y) > thr) continue;
             enter((int)e.x);
@@ -262,7 +272,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     // The fast-tree kernels (incoherent rays, deep walks) take the vote loop; the exact kernels (camera rays on small
     // scenes, re-runs) keep the while-while form below, which measured faster for coherent rays (Cornell camera
     // rays 0.63 vs 0.67 ms).
-    constexpr bool VOTE = MIRT_VOTE_LOOP && FAST;
+    constexpr bool VOTE = FAST;
     if constexpr (VOTE) {
     // ---- one loop, one kind of work per iteration, chosen by majority ---------------------------------------
     // Each iteration the wave does EITHER one traversal step for the lanes standing on an inner node OR one leaf
@@ -279,7 +289,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 uint32_t base = wave_id * RAY_CHUNK;
                 if (!first_chunk) {
                     const int leader = __ffsll((long long)need) - 1;
-                    if ((int)lane == leader) base = atomicAdd(queue, RAY_CHUNK);
+                    if ((int)lane_id() == leader) base = atomicAdd(queue, RAY_CHUNK);
                     base = __shfl(base, leader) + total_waves * RAY_CHUNK;
                 }
                 first_chunk = false;
@@ -291,7 +301,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 }
             }
             const uint32_t take = min(pool_end - pool_next, (uint32_t)__popcll(need));
-            const uint32_t rank = __popcll(need & lt_mask);
+            const uint32_t rank = rank_in(need);
             if (!active && rank < take) {
                 idx = pool_next + rank;
                 if (ray_list) idx = ray_list[idx];
@@ -333,7 +343,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         const int n_node = (int)__popcll(__ballot(want_node)), n_leaf = (int)__popcll(__ballot(want_leaf));
         if (n_node > 0 && n_node * MIRT_VOTE_NODE_WEIGHT >= n_leaf * MIRT_VOTE_LEAF_WEIGHT) {
             // ---- one traversal step for the lanes on an inner node ------------------------------------------
-            if (COUNT && lane == 0) au.w_inner++;
+            if (COUNT && lane_id() == 0) au.w_inner++;
 #pragma unroll
             for (int rep = 0; rep < MIRT_NODE_REPS; rep++)
             if (active && has && link >= 0) {
@@ -368,7 +378,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                     if ((uint32_t)sp < lds_levels)
                         stk[sp * bs] = e;
                     else
-                        stk_deep[(sp - lds_levels) * deep_stride] = e;
+                        *stk_deep(sp - lds_levels) = e;
                     sp++;
                 }
                 if (vl | vr)
@@ -377,64 +387,47 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                     pop();
             }
         } else if (n_leaf > 0) {
-            // ---- one leaf pass for the lanes on a leaf: up to LEAF_BATCH triangles; in NO_SELF mode a lane stops
-            // at its first candidate and the predicate runs once for all such lanes together -----------------------
-            int cand = -1;
-            const int leaf_beg = (int)(~(uint32_t)link & 0xFFFFFFu);
-            TriRec T;
-            {
-                // wave-level trips, one triangle per scanning lane and trip: the edge signs only (tri_inside); a lane
-                // whose line passes through a triangle stops there. The pass ends when every lane is through its
-                // share or, after the first trip, when fewer than MIRT_LEAF_QUORUM / 8 of the lanes that started are
-                // still scanning (the rest resume in the next leaf pass)
-                const int stop = want_leaf ? min(leaf_pos + LEAF_BATCH, leaf_end) : 0;
-                bool scanning = want_leaf && leaf_pos < stop;
-                for (int trip = 0; trip < LEAF_BATCH; trip++) {
-                    const int n_scan = (int)__popcll(__ballot(scanning));
-                    if (n_scan == 0 || (trip > 0 && n_scan * 8 < n_leaf * MIRT_LEAF_QUORUM)) break;
-                    if (COUNT && lane == 0) au.w_leaf++;
-                    if (scanning) {
-                        const int s = leaf_pos;
-#if MIRT_TRI_KEEP
-                        T = sc.tris[s];  // (a lane that stops keeps its last record in registers for the plane part)
-#else
-                        T.x = sc.tris[s].x;
-                        T.y = sc.tris[s].y;
-                        T.z = sc.tris[s].z;
-#endif
-                        if (COUNT) au.tri++;
-                        leaf_pos = s + 1;
-                        scanning = leaf_pos < stop;
-                        if (tri_inside(T.x, T.y, T.z, pre2)) {
-                            cand = s;
-                            scanning = false;
+            // ---- one leaf pass: the fast tree's leaves are single triangles (build_fast_tree). The edge signs first
+            // (tri_inside); for the lanes whose line passes through their triangle the distance (one division), the
+            // tie rule and, in NO_SELF mode, the predicate. A lane whose next node is a leaf again takes part in the
+            // next repetition of the pass. ------------------------------------------------------------------------
+#pragma unroll
+            for (int rep = 0; rep < MIRT_LEAF_REPS; rep++) {
+                const bool on_leaf = active && has && link < 0;
+                if (rep > 0 && (int)__popcll(__ballot(on_leaf)) * 8 < n_leaf * MIRT_LEAF_QUORUM) break;
+                if (COUNT && lane_id() == 0) au.w_leaf++;
+                const int s = (int)(~(uint32_t)link & 0xFFFFFFu);
+                bool through = false;
+                if (on_leaf) {
+                    if (COUNT) au.tri++;
+                    const TriRec* __restrict__ T = sc.tris + s;
+                    through = tri_inside(T->x, T->y, T->z, pre2);
+                }
+                if (through) {
+                    const TriRec T = sc.tris[s];
+                    const float t = tri_plane(T.n, tri_v2(T), o, d);
+                    bool hit = t >= 0.f;
+                    if (ANYHIT && t - lim >= -1e-5f) hit = false;  // at or beyond the limit: no occluder
+                    // (a tie goes to the larger rank, DevScene::tie_rank: the position of a fast-tree leaf says
+                    // nothing about the reference's order of leaves and triangles)
+                    bool better = best_slot < 0 || t < best;
+                    if (hit && !better && t == best) better = sc.tie_rank[s] > sc.tie_rank[best_slot];
+                    hit = hit && better;
+                    if (MODE == MIRT_MODE_NO_SELF) {
+                        if (hit) {
+                            const VnRec V = sc.vns[s];
+                            const f3 pos = o + d * t;
+                            const float dn = noself_dn<BUMP>(sc, T, V, s, pos, d);
+                            if (legal_noself(dn, __float_as_int(V.n0.w), unpack_contact(a), unpack_inside(a)))
+                                accept(t, s);
                         }
+                    } else if (hit && !(MODE == MIRT_MODE_LAST_TID && __float_as_int(sc.vns[s].n1.w) == a)) {
+                        accept(t, s);
                     }
                 }
-                if (COUNT && lane == 0) au.w_outer++;
+                if (on_leaf && has) pop();  // (an any-hit ray that found its occluder has nothing left to visit)
             }
-            // the distance (one division) and, in NO_SELF mode, the predicate: once per pass, for the lanes that stopped
-            if (cand >= 0) {
-#if !MIRT_TRI_KEEP
-                T = sc.tris[cand];
-#endif
-                const float t = tri_plane(T.n, tri_v2(T), o, d);
-                bool hit = t >= 0.f;
-                if (ANYHIT && t - lim >= -1e-5f) hit = false;  // at or beyond the limit: no occluder
-                hit = hit && (best_slot < 0 || t < best || (t == best && best_slot < leaf_beg));
-                if (MODE == MIRT_MODE_NO_SELF) {
-                    if (hit) {
-                        const VnRec V = sc.vns[cand];
-                        const f3 pos = o + d * t;
-                        const float dn = noself_dn<BUMP>(sc, T, V, cand, pos, d);
-                        if (legal_noself(dn, __float_as_int(V.n0.w), unpack_contact(a), unpack_inside(a)))
-                            accept(t, cand);
-                    }
-                } else if (hit && !(MODE == MIRT_MODE_LAST_TID && __float_as_int(sc.vns[cand].n1.w) == a)) {
-                    accept(t, cand);
-                }
-            }
-            if (want_leaf && has && leaf_pos >= leaf_end) pop();
+            if (COUNT && lane_id() == 0) au.w_outer++;
         }
 
         // ---- retire finished rays -----------------------------------------------------------------
@@ -466,7 +459,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 uint32_t base = wave_id * RAY_CHUNK;
                 if (!first_chunk) {
                     const int leader = __ffsll((long long)need) - 1;
-                    if ((int)lane == leader) base = atomicAdd(queue, RAY_CHUNK);
+                    if ((int)lane_id() == leader) base = atomicAdd(queue, RAY_CHUNK);
                     base = __shfl(base, leader) + total_waves * RAY_CHUNK;
                 }
                 first_chunk = false;
@@ -478,7 +471,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 }
             }
             const uint32_t take = min(pool_end - pool_next, (uint32_t)__popcll(need));
-            const uint32_t rank = __popcll(need & lt_mask);
+            const uint32_t rank = rank_in(need);
             if (!active && rank < take) {
                 idx = pool_next + rank;
                 if (ray_list) idx = ray_list[idx];
@@ -520,7 +513,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             const bool go = active && has && link >= 0;
             if (COUNT) {  // same loop, written so that whole-wave iterations can be counted
                 if (!__any(go)) break;
-                if (lane == 0) au.w_inner++;
+                if (lane_id() == 0) au.w_inner++;
                 if (!go) continue;
             } else if (!go) {
                 break;
@@ -557,7 +550,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 if ((uint32_t)sp < lds_levels)
                     stk[sp * bs] = e;
                 else
-                    stk_deep[(sp - lds_levels) * deep_stride] = e;
+                    *stk_deep(sp - lds_levels) = e;
                 sp++;
             }
             if (vl | vr)
@@ -572,7 +565,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         if (COUNT) {
             int trips = (active && has) ? min(LEAF_BATCH, leaf_end - leaf_pos) : 0;
             for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off));
-            if (lane == 0) {
+            if (lane_id() == 0) {
                 au.w_leaf += trips;
                 au.w_outer++;
             }
@@ -647,7 +640,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             au.bad += __shfl_down(au.bad, off);
             au.walk += __shfl_down(au.walk, off);
         }
-        if (lane == 0) {
+        if (lane_id() == 0) {
             atomicAdd(&counters[5], au.w_inner);
             atomicAdd(&counters[6], au.w_leaf);
             atomicAdd(&counters[7], au.w_outer);

@@ -392,38 +392,41 @@ static bool bounds_in_model(const TreeView& s) {
 }
 
 // ---- the fast tree ---------------------------------------------------------------------------------
-// A second hierarchy over the REFERENCE tree's leaves (their slot ranges and their boxes, unchanged),
-// built here with a binned surface-area heuristic. The reference's median split on vertex coordinates
-// makes a ray walk several root-to-leaf chains of heavily overlapping boxes (112 box tests per ray on
-// the 1 M-triangle scene); grouping the same leaves by surface area roughly halves that. The traversal
-// kernel walks THIS tree with a conservative box test and so sees a superset of the leaves the
-// reference would reach; k_verify then proves the winner's chain of reference boxes with the
-// reference's own test (DESIGN.md "fast tree"). Output: a pre-order TreeView (left child = i + 1)
-// whose leaves carry reference leaf slot ranges.
+// A second hierarchy over the scene's TRIANGLES (each in the device slot the reference tree's leaf order gives
+// it, each a leaf of its own with the box of its three corners), built here with a binned surface-area
+// heuristic. The reference's median split on vertex coordinates makes a ray walk several root-to-leaf chains
+// of heavily overlapping boxes (112 box tests per ray on the 1 M-triangle scene) and test every triangle of
+// every leaf it reaches (12 per ray); a hierarchy built by surface area over the triangles themselves roughly
+// halves the first and divides the second by three. The traversal kernel walks THIS tree with a conservative
+// box test and so tests a superset of the triangles the reference would reach (a triangle the reference test
+// accepts is crossed by the ray inside its own box, up to a rounding the slab margin covers); k_verify then
+// proves the winner's chain of REFERENCE boxes with the reference's own test, and ties between triangles
+// follow the reference's order through DevScene::tie_rank (DESIGN.md "fast tree"). Output: a pre-order
+// TreeView (left child = i + 1) whose leaves are single slots.
 struct FastTree {
     std::vector<float> mn, mx;
     std::vector<int32_t> right, lbeg, lend;
     int depth = 0;
 };
 
-static void build_fast_tree(const TreeView& ref, FastTree& ft) {
+// slot_box(slot, mn, mx) widens mn / mx by the triangle in that device slot.
+static void build_fast_tree(const TreeView& ref, FastTree& ft, const std::function<void(int, float*, float*)>& slot_box) {
     struct Leaf {
         float mn[3], mx[3], c[3];
         int b, e;
     };
     std::vector<Leaf> leaves;
     for (int i = 0; i < ref.N; i++)
-        if (ref.right[i] < 0 && ref.lend[i] > ref.lbeg[i]) {
-            Leaf l;
-            for (int k = 0; k < 3; k++) {
-                l.mn[k] = ref.mn[3 * i + k];
-                l.mx[k] = ref.mx[3 * i + k];
-                l.c[k] = 0.5f * (l.mn[k] + l.mx[k]);
+        if (ref.right[i] < 0)
+            for (int t = ref.lbeg[i]; t < ref.lend[i]; t++) {
+                Leaf l;
+                l.b = t;
+                l.e = t + 1;
+                for (int k = 0; k < 3; k++) l.mn[k] = INFINITY, l.mx[k] = -INFINITY;
+                slot_box(t, l.mn, l.mx);
+                for (int k = 0; k < 3; k++) l.c[k] = 0.5f * (l.mn[k] + l.mx[k]);
+                leaves.push_back(l);
             }
-            l.b = ref.lbeg[i];
-            l.e = ref.lend[i];
-            leaves.push_back(l);
-        }
     if (leaves.empty()) return;
     auto area = [](const float* mn, const float* mx) {
         const double dx = (double)mx[0] - mn[0], dy = (double)mx[1] - mn[1], dz = (double)mx[2] - mn[2];
@@ -766,11 +769,12 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
             slot_base += s->objects[obj_trees[k].object].tri_count;
         }
     }
+    const std::vector<int> main_src = seam_order(main_tree);  // device slot -> position in the reference's slot order
     // fast tree over the reference leaves + the reference nodes with parent links for k_verify
     std::vector<PairRec> fpairs;
     float4 froot_lo = root_lo, froot_hi = root_hi;
     std::vector<NodeRec> rnodes(N);
-    std::vector<int> slot_node(std::max(T, 1), 0);
+    std::vector<int> slot_node(2 * (size_t)std::max(T, 1), 0);  // [0, T): leaf node of a slot; [T, 2T): its tie rank
     bool use_fast = true;
     if (const char* e = getenv("MIRT_FAST_TREE")) use_fast = atoi(e) != 0;  // A/B switch
     {
@@ -782,6 +786,18 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
             } else {
                 for (int k = s->node_leaf_begin[i]; k < s->node_leaf_end[i]; k++) slot_node[k] = i;
             }
+        {
+            // DevScene::tie_rank, per DEVICE slot (main_src: device slot -> position in the reference's slot order)
+            std::vector<int> leaf_b(std::max(T, 1), 0), leaf_e(std::max(T, 1), 0);
+            for (int i = 0; i < N; i++)
+                if (s->node_right[i] < 0)
+                    for (int k = s->node_leaf_begin[i]; k < s->node_leaf_end[i]; k++)
+                        leaf_b[k] = s->node_leaf_begin[i], leaf_e[k] = s->node_leaf_end[i];
+            for (int k = 0; k < T; k++) {
+                const int r = main_src[k];
+                slot_node[(size_t)std::max(T, 1) + k] = leaf_b[r] + (leaf_e[r] - 1 - r);
+            }
+        }
         for (int i = 0; i < N; i++) {
             const float* mn = s->node_min + 3 * i;
             const float* mx = s->node_max + 3 * i;
@@ -794,7 +810,14 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         }
         if (use_fast) {
             FastTree ft;
-            build_fast_tree(main_tree, ft);
+            build_fast_tree(main_tree, ft, [&](int slot, float* mn, float* mx) {
+                const float* p = s->tri_pos + 9 * (size_t)s->slot_tid[main_src[slot]];
+                for (int v = 0; v < 3; v++)
+                    for (int k = 0; k < 3; k++) {
+                        mn[k] = std::min(mn[k], p[3 * v + k]);
+                        mx[k] = std::max(mx[k], p[3 * v + k]);
+                    }
+            });
             if (ft.right.empty()) {
                 use_fast = false;
             } else {
@@ -838,7 +861,6 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         const float d12 = hdot(b1, b2), l1 = sqrtf(hdot(b1, b1)), l2 = sqrtf(hdot(b2, b2));
         vns[k].w = make_float4(l1, d12, d12 * d12 - l1 * l1 * l2 * l2, l1 * l1);
     };
-    const std::vector<int> main_src = seam_order(main_tree);  // device slot -> position in the reference's slot order
     for (int k = 0; k < T; k++) fill_slot((size_t)k, s->slot_tid[main_src[k]]);
     std::vector<VtRec> vts(tri_vt ? TT : 0);
     auto fill_vt = [&](size_t k, int g) {
@@ -954,6 +976,7 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     ctx->sc.froot_hi = froot_hi;
     ctx->sc.rnodes = ctx->d_rnodes;
     ctx->sc.slot_node = ctx->d_slot_node;
+    ctx->sc.tie_rank = ctx->d_slot_node + std::max(T, 1);
     // (a scene outside the classifier's model, fast_ok = 0, would have every ray skipped by the fast walk, listed
     // by k_verify and re-run exactly: it stays on the reference tree alone)
     ctx->fast_tree = use_fast && fast_ok;
@@ -1400,8 +1423,17 @@ int mirt_fast_tree(const MirtSceneDesc* s, int32_t capacity_nodes, int32_t* n_no
         g_create_err = "mirt_fast_tree: " + why;
         return MIRT_E_INVALID;
     }
+    if (s->n_tris > 0 && (!s->tri_pos || !s->slot_tid)) return MIRT_E_INVALID;
     FastTree ft;
-    build_fast_tree(view, ft);
+    const std::vector<int> src = seam_order(view);  // device slot -> position in the reference's slot order
+    build_fast_tree(view, ft, [&](int slot, float* mn, float* mx) {
+        const float* p = s->tri_pos + 9 * (size_t)s->slot_tid[src[slot]];
+        for (int v = 0; v < 3; v++)
+            for (int k = 0; k < 3; k++) {
+                mn[k] = std::min(mn[k], p[3 * v + k]);
+                mx[k] = std::max(mx[k], p[3 * v + k]);
+            }
+    });
     const int32_t n = (int32_t)ft.right.size();
     *n_nodes_out = n;
     if (n > capacity_nodes) return MIRT_E_LIMIT;
@@ -1412,8 +1444,9 @@ int mirt_fast_tree(const MirtSceneDesc* s, int32_t capacity_nodes, int32_t* n_no
             node_max[3 * i + c] = ft.mx[3 * i + c];
         }
         node_right[i] = ft.right[i];
-        leaf_begin[i] = ft.lbeg[i];
-        leaf_end[i] = ft.lend[i];
+        // a leaf is one triangle, given by its position in the reference's slot order
+        leaf_begin[i] = ft.lbeg[i] >= 0 ? src[ft.lbeg[i]] : -1;
+        leaf_end[i] = ft.lbeg[i] >= 0 ? src[ft.lbeg[i]] + 1 : -1;
     }
     return MIRT_OK;
 }

@@ -127,6 +127,10 @@ struct DevScene {
     float4 froot_lo, froot_hi;
     const NodeRec* rnodes;
     const int* slot_node;      // reference leaf node of every slot of the scene tree
+    // distance ties in the fast-tree kernels, whose leaves are single triangles: of two hits at the same distance the
+    // one with the larger rank is the reference's answer (between leaves the later one, KDTree.cpp:319-320; inside
+    // a leaf the earlier triangle, KDTree.cpp:305): rank = leaf begin + (leaf end - 1 - position in the leaf)
+    const int* tie_rank;
     const DevLight* lights;    // emission sampler (PathTracerTest's light connections)
     const float* light_area;   // running triangle areas per light object (SceneObject::areaValues)
     const int* light_slot;     // slot of each light triangle

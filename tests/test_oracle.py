@@ -391,21 +391,22 @@ def test_phong_known_answers(orc, ra):
 
 
 def test_fast_tree_and_its_restatement(cornell, cornell_oracle, mesh20k, mesh20k_oracle):
-    """mirt_fast_tree (host-only): a binary hierarchy in which every leaf of the scene tree appears exactly
-    once with its slot range and box, and every node box is the union of its children's; the oracle's
-    restatement of the fast path over it (conservative traversal + reference-chain check + exact re-run)
-    returns exactly the reference closest hit, with fewer box tests than the reference tree needs."""
+    """mirt_fast_tree (host-only): a binary hierarchy in which every triangle slot of the scene tree appears
+    exactly once, as a leaf of its own with the box of its three corners, and every node box is the union of its
+    children's; the oracle's restatement of the fast path over it (conservative traversal + reference-chain
+    check + exact re-run) returns exactly the reference closest hit, with fewer box tests than the reference
+    tree needs."""
     for scene, S, nobj, inside in ((cornell, cornell_oracle, 8, 2), (mesh20k, mesh20k_oracle, 9, 8)):
         ref, ft = scene.tree(), scene.fast_tree()
         right, lb, le = ft["node_right"], ft["leaf_begin"], ft["leaf_end"]
         leaf = right < 0
-        ref_leaf = ref["node_right"] < 0
-        assert sorted(zip(lb[leaf].tolist(), le[leaf].tolist())) == sorted(
-            zip(ref["leaf_begin"][ref_leaf].tolist(), ref["leaf_end"][ref_leaf].tolist()))
-        key = {(b, e): i for i, (b, e) in enumerate(zip(ref["leaf_begin"].tolist(), ref["leaf_end"].tolist())) if ref_leaf[i]}
+        assert sorted(lb[leaf].tolist()) == list(range(scene.n_tris)) and np.array_equal(le[leaf], lb[leaf] + 1)
+        assert len(right) == 2 * scene.n_tris - 1
+        raw = scene.raw()
+        pos = raw["verts"][raw["tris"].astype(np.int64)]  # [T, 3 corners, xyz], by global triangle id
         for i in np.nonzero(leaf)[0][:200]:
-            j = key[(int(lb[i]), int(le[i]))]
-            assert np.array_equal(ft["node_min"][i], ref["node_min"][j]) and np.array_equal(ft["node_max"][i], ref["node_max"][j])
+            p = pos[ref["slot_tid"][lb[i]]]
+            assert np.array_equal(ft["node_min"][i], p.min(0)) and np.array_equal(ft["node_max"][i], p.max(0))
         inner = np.nonzero(~leaf)[0]
         l, r = inner + 1, right[inner]
         assert (r > l).all() and (r < len(right)).all()
