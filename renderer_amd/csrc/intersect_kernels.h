@@ -50,9 +50,6 @@ namespace mirt {
 #ifndef MIRT_RAY_CHUNK_MIN_RAYS
 #define MIRT_RAY_CHUNK_MIN_RAYS (1u << 20)
 #endif
-#ifndef MIRT_TRI_KEEP
-#define MIRT_TRI_KEEP 0  // 1: a lane that stops at a triangle keeps the record in registers for the plane part
-#endif
 #ifndef MIRT_LEAF_BATCH
 #define MIRT_LEAF_BATCH 8
 #endif
@@ -62,27 +59,27 @@ namespace mirt {
 // 256, 0.74 at 512), bounce rays barely (3.70 / 3.68 / 3.76 / 4.07 ms). Small launches keep 64 so that every wave
 // of the grid gets work.
 constexpr uint32_t RAY_CHUNK_SMALL = MIRT_RAY_CHUNK;
-// MIRT_VOTE_LOOP: the traversal loop does one kind of work per iteration, chosen by majority vote of the wave's lanes
-// (k_intersect); 0 = the while-while form (every lane descends until all stand on a leaf, then all test triangles).
-#ifndef MIRT_VOTE_LOOP
-#define MIRT_VOTE_LOOP 1
-#endif
+// The fast-tree kernels' loop does one kind of work per iteration, chosen by majority vote of the wave's lanes (the
+// exact kernels keep the while-while form: every lane descends until all stand on a leaf, then all test triangles).
 #ifndef MIRT_REFILL_MIN
-#define MIRT_REFILL_MIN 16  // idle lanes that trigger a refill (a refill also happens whenever no lane has work left)
+#define MIRT_REFILL_MIN 24  // idle lanes that trigger a refill (a refill also happens whenever no lane has work left)
 #endif
 // a traversal step runs when (lanes on inner nodes) * NODE_WEIGHT >= (lanes on leaves) * LEAF_WEIGHT, else a leaf pass.
 // Swept on the 12.6 M-ray bounce batches (Cornell / 1 M triangles, ms): 1:1 3.45 / 5.62, 2:1 3.26 / 5.63, 3:1 3.31 / 5.90,
 // 4:1 3.36 / 6.14, 1:2 3.74 / 5.92 (leaf batch 3-4, refill at 16 idle lanes; the while-while form: 3.52 / 7.19).
 // Again with the triangle test split (edge signs per trip, plane part once per pass): 2:1 2.47 / 4.42, 3:2 2.45 / 4.30,
-// 1:1 2.49 / 4.29.
+// 1:1 2.49 / 4.29; with single-triangle leaves: 2:1 1.83 / 3.49, 3:2 1.79 / 3.42, 1:1 1.79 / 3.38.
 #ifndef MIRT_VOTE_NODE_WEIGHT
 #define MIRT_VOTE_NODE_WEIGHT 3
 #endif
-#ifndef MIRT_LEAF_QUORUM
-#define MIRT_LEAF_QUORUM 2  // eighths of the leaf lanes that must still be scanning for another trip of a leaf pass
-#endif
+// triangles per leaf pass (a lane goes on when its next node is a leaf again): bounce rays 1, coherent rays 2.
+// Swept, Cornell / 1 M triangles / fog, mode-2 call in ms: 1 1.79 / 3.42 / 1.64, 2 1.82 / 3.55 / 1.70, 4 1.77 / 3.44 / 1.63;
+// 4 Mi camera rays: 1 0.42 / 0.755 / 0.48, 2 0.405 / 0.745 / 0.457.
 #ifndef MIRT_LEAF_REPS
-#define MIRT_LEAF_REPS 2  // triangles per leaf pass (a lane goes on when its next node is a leaf again)
+#define MIRT_LEAF_REPS 1
+#endif
+#ifndef MIRT_LEAF_REPS_COHERENT
+#define MIRT_LEAF_REPS_COHERENT 2
 #endif
 #ifndef MIRT_NODE_REPS
 #define MIRT_NODE_REPS 3  // traversal steps per node pass (lanes that reach a leaf sit the rest out)
@@ -94,11 +91,8 @@ constexpr uint32_t RAY_CHUNK_SMALL = MIRT_RAY_CHUNK;
 #define MIRT_FAST_BUDGET 16
 #endif
 constexpr int FAST_AMBIGUOUS_BUDGET = MIRT_FAST_BUDGET;  // k_intersect<FAST>: unproven boxes a ray may enter before it is handed to the exact kernel
-#ifndef MIRT_LEAF_BATCH_FAST
-#define MIRT_LEAF_BATCH_FAST 6
-#endif
-// triangles a lane tests per leaf phase before the wave regroups (exact kernels / fast-tree kernels: swept separately)
-constexpr int LEAF_BATCH_EXACT = MIRT_LEAF_BATCH, LEAF_BATCH_FAST = MIRT_LEAF_BATCH_FAST;
+// triangles a lane tests per leaf phase before the wave regroups (the exact kernels; a fast-tree leaf is one triangle)
+constexpr int LEAF_BATCH_EXACT = MIRT_LEAF_BATCH;
 
 struct Audit {
     unsigned long long box = 0, tri = 0, amb = 0, bad = 0, walk = 0;
@@ -161,7 +155,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             const float* __restrict__ limit = nullptr, unsigned char* __restrict__ vis_out = nullptr,
             const uint32_t* __restrict__ ray_list = nullptr, uint32_t list_min = 0) {
     extern __shared__ uint32_t lds[];
-    constexpr int LEAF_BATCH = FAST ? LEAF_BATCH_FAST : LEAF_BATCH_EXACT;
+    constexpr int LEAF_BATCH = LEAF_BATCH_EXACT;
     const PairRec* __restrict__ pairs = FAST ? sc.fpairs : sc.pairs;
     const float4 root_lo = FAST ? sc.froot_lo : sc.root_lo, root_hi = FAST ? sc.froot_hi : sc.root_hi;
     // ray count: given, or (wavefront path tracer) left in device memory by the previous shade pass
@@ -392,9 +386,9 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             // tie rule and, in NO_SELF mode, the predicate. A lane whose next node is a leaf again takes part in the
             // next repetition of the pass. ------------------------------------------------------------------------
 #pragma unroll
-            for (int rep = 0; rep < MIRT_LEAF_REPS; rep++) {
+            for (int rep = 0; rep < (MODE == MIRT_MODE_NO_SELF ? MIRT_LEAF_REPS : MIRT_LEAF_REPS_COHERENT); rep++) {
                 const bool on_leaf = active && has && link < 0;
-                if (rep > 0 && (int)__popcll(__ballot(on_leaf)) * 8 < n_leaf * MIRT_LEAF_QUORUM) break;
+                if (rep > 0 && !__any(on_leaf)) break;
                 if (COUNT && lane_id() == 0) au.w_leaf++;
                 const int s = (int)(~(uint32_t)link & 0xFFFFFFu);
                 bool through = false;
