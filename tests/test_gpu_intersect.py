@@ -680,3 +680,51 @@ def test_grazing_rays_divergence_is_bounded(gpu, cornell, cornell_oracle, ra):
                 nn /= np.linalg.norm(nn)
                 worst = min(worst, abs(float(nn @ d[:, k].astype(np.float64))))
             assert worst < 1e-3, (k, ig[k], ic[k], tg[k], tc[k], worst)
+
+
+def test_coplanar_rays_divergence_is_bounded(gpu, mesh20k, mesh20k_oracle, ra):
+    """A ray that lies IN the plane of a triangle (to within rounding) has all three edge signs and both terms
+    of the plane distance at rounding-noise level: the reference's triangle test (KDTree.cpp:267-289) is then
+    decided by that noise and may report a hit anywhere along the ray, far outside the triangle. The fast tree
+    keeps every triangle in the box of its own corners, so such a triangle is only tested when the ray crosses
+    that box; the reference tests it whenever it reaches the triangle's leaf. These rays (origin and direction
+    both in a triangle's plane, or tilted out of it by 1e-7 .. 1e-5 rad) are the extreme case of the north
+    star's "grazing rays": the ids must agree on all but a small share of them, and every differing ray must
+    have such a coplanar triangle on one side."""
+    n = 200000
+    rng = np.random.default_rng(21)
+    raw = mesh20k.raw()
+    V = raw["verts"][raw["tris"].astype(np.int64)].astype(np.float64)  # [T, 3, 3]
+    tid = rng.integers(0, len(V), n)
+    v0, v1, v2 = V[tid, 0], V[tid, 1], V[tid, 2]
+    nn = np.cross(v1 - v0, v2 - v1)
+    nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+    e1 = (v1 - v0) / np.linalg.norm(v1 - v0, axis=1, keepdims=True)
+    e2 = np.cross(nn, e1)
+    size = np.linalg.norm(v1 - v0, axis=1)
+    cen = (v0 + v1 + v2) / 3
+    a1, a2 = rng.uniform(0, 2 * np.pi, n), rng.uniform(0, 2 * np.pi, n)
+    o = cen + (np.cos(a1)[:, None] * e1 + np.sin(a1)[:, None] * e2) * (size * rng.uniform(0.5, 4.0, n))[:, None]
+    d = np.cos(a2)[:, None] * e1 + np.sin(a2)[:, None] * e2
+    tilt = np.where(rng.random(n) < 0.5, 0.0, 10.0 ** rng.uniform(-7, -5, n) * rng.choice([-1.0, 1.0], n))
+    d = d + tilt[:, None] * nn
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o, d = np.ascontiguousarray(o.T, np.float32), np.ascontiguousarray(d.T, np.float32)
+    aux = ra.pack_ids(np.full(n, -1), np.full(n, -1))
+    gpu.upload(mesh20k.describe())
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_NO_SELF, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = mesh20k_oracle.intersect(o, d, a, mode, threads=16)
+        diff = np.nonzero(ig != ic)[0]
+        print("mode %d: %d of %d coplanar rays differ" % (mode, len(diff), n))
+        assert len(diff) <= 2e-3 * n, "mode %d: %d of %d coplanar rays differ" % (mode, len(diff), n)
+        for k in diff[:2000]:
+            worst = 1.0
+            for t in (ig[k], ic[k]):
+                if t < 0:
+                    continue
+                w = V[t]
+                m = np.cross(w[1] - w[0], w[2] - w[1])
+                m /= np.linalg.norm(m)
+                worst = min(worst, abs(float(m @ d[:, k].astype(np.float64))))
+            assert worst < 1e-4, (k, ig[k], ic[k], tg[k], tc[k], worst)
