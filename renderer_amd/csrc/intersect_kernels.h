@@ -176,6 +176,9 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     lds_u64* stk = (lds_u64*)lds + threadIdx.x;
     // (the deep levels' address is put together where it is used, rarely: two more VGPRs saved)
     const size_t deep_stride = (size_t)gridDim.x * bs;
+    // (blockDim.x is a power of two: mirt.hip launches 64 .. 256 lanes per block)
+    const uint32_t level_shift = 3u + (31u - (uint32_t)__builtin_clz(bs)), level_bytes = 1u << level_shift;
+    const uint32_t lds_bytes = lds_levels << level_shift;
     auto stk_deep = [&](uint32_t level) -> glb_u64* {
         return (glb_u64*)spill + ((size_t)blockIdx.x * bs + threadIdx.x) + (size_t)level * deep_stride;
     };
@@ -199,7 +202,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
     int a = 0;
     float best = -1.f, thr = INF;  // thr: entry distances beyond it cannot beat the closest hit (prune())
-    int best_slot = -1, sp = 0, link = 0;
+    int best_slot = -1, link = 0;
+    uint32_t sp = 0;  // stack depth as the BYTE offset of the next free LDS level (level * blockDim * 8)
     int leaf_pos = 0, leaf_end = 0;  // triangles still to test in the current leaf
     int unproven = 0;                // FAST: boxes entered without proof so far
     float lim = 0.f;                 // ANYHIT: distance limit of this ray
@@ -237,14 +241,14 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     auto pop = [&]() {  // next node from the stack; entries beyond the closest hit are dropped
         has = false;
         while (sp > 0) {
-            sp--;
+            sp -= level_bytes;
             // (two loads in two address spaces, on purpose: a select between the pointers would go through a
             // generic pointer, and its aperture test trips this compiler at higher occupancy targets)
             unsigned long long packed;
-            if ((uint32_t)sp < lds_levels)
-                packed = stk[sp * bs];
+            if (sp < lds_bytes)
+                packed = *(lds_u64*)((__attribute__((address_space(3))) char*)stk + sp);
             else
-                packed = *stk_deep(sp - lds_levels);
+                packed = *stk_deep((sp - lds_bytes) >> level_shift);
             const uint2 e = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
             if (__uint_as_float(e.y) > thr) continue;
             enter((int)e.x);
@@ -344,9 +348,16 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 const PairRec P = pairs[link];
                 float lbl, lbr;
                 // conservative: only a proven miss is skipped (slab_miss_pair, mirt_dev.h)
-                bool ul, ur;
-                bool vl = !slab_miss_pair(P.la, P.lb, pre2, pre, lbl, ul);
-                bool vr = !slab_miss_pair(P.ra, P.rb, pre2, pre, lbr, ur);
+                // (boxes entered on the margin alone are counted in the first step of a node pass only: a ray the
+                // budget is for enters such boxes at every step, and the bookkeeping is ~9 instructions of ~60)
+                bool ul, ur, vl, vr;
+                if (COUNT || rep == 0) {
+                    vl = !slab_miss_pair<true>(P.la, P.lb, pre2, pre, lbl, ul);
+                    vr = !slab_miss_pair<true>(P.ra, P.rb, pre2, pre, lbr, ur);
+                } else {
+                    vl = !slab_miss_pair<false>(P.la, P.lb, pre2, pre, lbl, ul);
+                    vr = !slab_miss_pair<false>(P.ra, P.rb, pre2, pre, lbr, ur);
+                }
                 if (COUNT) {  // audit: a reported miss that the reference test does not share must never happen
                     au.box += 2;
                     au.amb += (int)ul + (int)ur;
@@ -356,11 +367,13 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 // A ray whose margin is wide (a nearly axis-parallel direction: |1/d| ~ 1e9) can prove almost no
                 // miss and would walk the whole tree: after FAST_AMBIGUOUS_BUDGET boxes entered on the margin alone
                 // it is given up and left to the exact kernel (slot -2 tells k_verify).
-                unproven += (int)ul + (int)ur;
-                if (unproven > FAST_AMBIGUOUS_BUDGET) {
-                    vl = vr = false;
-                    sp = 0;
-                    best_slot = -2;
+                if (COUNT || rep == 0) {
+                    unproven += (int)ul + (int)ur;
+                    if (unproven > FAST_AMBIGUOUS_BUDGET) {
+                        vl = vr = false;
+                        sp = 0;
+                        best_slot = -2;
+                    }
                 }
                 vl &= !(lbl > thr);
                 vr &= !(lbr > thr);
@@ -369,11 +382,11 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 if (vl & vr) {
                     const unsigned long long e = (unsigned long long)(uint32_t)(pick_l ? kr : kl) |
                                                  ((unsigned long long)__float_as_uint(pick_l ? lbr : lbl) << 32);
-                    if ((uint32_t)sp < lds_levels)
-                        stk[sp * bs] = e;
+                    if (sp < lds_bytes)
+                        *(lds_u64*)((__attribute__((address_space(3))) char*)stk + sp) = e;
                     else
-                        *stk_deep(sp - lds_levels) = e;
-                    sp++;
+                        *stk_deep((sp - lds_bytes) >> level_shift) = e;
+                    sp += level_bytes;
                 }
                 if (vl | vr)
                     enter(pick_l ? kl : kr);
@@ -541,11 +554,11 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             if (vl & vr) {
                 const unsigned long long e = (unsigned long long)(uint32_t)(pick_l ? kr : kl) |
                                              ((unsigned long long)__float_as_uint(pick_l ? lbr : lbl) << 32);
-                if ((uint32_t)sp < lds_levels)
-                    stk[sp * bs] = e;
+                if (sp < lds_bytes)
+                    *(lds_u64*)((__attribute__((address_space(3))) char*)stk + sp) = e;
                 else
-                    *stk_deep(sp - lds_levels) = e;
-                sp++;
+                    *stk_deep((sp - lds_bytes) >> level_shift) = e;
+                sp += level_bytes;
             }
             if (vl | vr)
                 enter(pick_l ? kl : kr);

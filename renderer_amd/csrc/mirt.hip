@@ -468,7 +468,12 @@ static void build_fast_tree(const TreeView& ref, FastTree& ft, const std::functi
             continue;
         }
         int mid = -1;
-        if (j.depth < 40) {  // beyond that depth fall back to halving the range, which bounds the depth
+        // surface-area splits only while halving the range could still finish inside the depth the kernels' stacks
+        // allow (a node of n triangles needs ceil(log2 n) more levels when halved): the depth is bounded whatever
+        // the geometry, and never by more than MIRT_MAX_TREE_DEPTH
+        int levels = 0;
+        while ((1ll << levels) < n) levels++;
+        if (j.depth < 40 && j.depth + 1 + levels < MIRT_MAX_TREE_DEPTH) {
             double best = INFINITY;
             int best_axis = -1, best_bin = -1;
             for (int k = 0; k < 3; k++) {

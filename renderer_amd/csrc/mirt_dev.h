@@ -400,6 +400,7 @@ __device__ __forceinline__ int slab_classify_pair(const float4 a, const float4 b
 // tn - err <= t <= tf + err, which tn - tf > M >= 2 err excludes. `unproven` tells the caller that the box was
 // entered only because of the margin (|tf - tn| <= M on a box that is not flat): a ray for which that keeps
 // happening (a nearly axis-parallel direction makes M enormous) is given up and left to the exact kernel.
+template <bool WANT_UNPROVEN = true>
 __device__ __forceinline__ bool slab_miss_pair(const float4 a, const float4 b, const RayPre2& q, const RayPre& p,
                                                float& lb, bool& unproven) {
     const v2f tx = pk_fma_b<0, 0>(v2f{a.x, a.y}, q.ixy, q.cxy);
@@ -411,7 +412,7 @@ __device__ __forceinline__ bool slab_miss_pair(const float4 a, const float4 b, c
     const float gap = tf - tn;
     lb = vmax(tn, 0.f);
     const bool miss = vmin(tf, gap) < -M;  // (tf < -M) | (gap < -M)
-    unproven = !miss & (__float_as_int(b.w) == 0) & !(gap > M);
+    unproven = WANT_UNPROVEN ? (!miss & (__float_as_int(b.w) == 0) & !(gap > M)) : false;
     return miss;
 }
 // k_verify's first look at a box of the winner's chain: a SUFFICIENT condition for "the reference test passes",
