@@ -410,6 +410,9 @@ struct FastTree {
 };
 
 // slot_box(slot, mn, mx) widens mn / mx by the triangle in that device slot.
+#ifndef MIRT_SAH_BINS
+#define MIRT_SAH_BINS 16
+#endif
 static void build_fast_tree(const TreeView& ref, FastTree& ft, const std::function<void(int, float*, float*)>& slot_box) {
     struct Leaf {
         float mn[3], mx[3], c[3];
@@ -432,7 +435,7 @@ static void build_fast_tree(const TreeView& ref, FastTree& ft, const std::functi
         const double dx = (double)mx[0] - mn[0], dy = (double)mx[1] - mn[1], dz = (double)mx[2] - mn[2];
         return 2.0 * (dx * dy + dy * dz + dz * dx);
     };
-    const int BINS = 16;
+    const int BINS = MIRT_SAH_BINS;
     // iterative pre-order construction: a node's right index is patched when its right child is emitted
     struct Job {
         int b, e, depth, parent;  // parent: node whose `right` this job fills (-1: left child or root)
