@@ -1803,7 +1803,7 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
             // PathTracerTest: shade writes one shadow ray per RANDOM vertex; the visibility launch and
             // k_connect add the unoccluded contributions before the next bounce touches L again
             uint32_t* n_sh = ctx->d_ns + depth;
-            hipLaunchKernelGGL((k_shade<false, true>), dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur,
+            hipLaunchKernelGGL((k_shade<false, true>), dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur,
                                n_in, bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth,
                                ctx->shb, n_sh);
             HIPCHK(ctx, hipGetLastError());
@@ -1813,10 +1813,10 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
             hipLaunchKernelGGL(k_connect, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->shb, n_sh, bound, ctx->d_L,
                                (uint32_t)ctx->pb_cap);
         } else if (ctx->has_media)
-            hipLaunchKernelGGL(k_shade<true>, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in,
+            hipLaunchKernelGGL(k_shade<true>, dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in,
                                bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth);
         else
-            hipLaunchKernelGGL(k_shade<false>, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in,
+            hipLaunchKernelGGL(k_shade<false>, dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in,
                                bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth);
         HIPCHK(ctx, hipGetLastError());
         depths_run = depth + 1;
@@ -1943,10 +1943,10 @@ static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderP
             const uint32_t* n_in = (it || counted_start) ? ctx->d_cnt + it : nullptr;
             uint32_t* n_out = ctx->d_cnt + it + 1;
             if (ctx->has_media)
-                hipLaunchKernelGGL(k_shade<true>, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
+                hipLaunchKernelGGL(k_shade<true>, dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
                                    n_out, ctx->d_L, (uint32_t)cap, prm->max_depth);
             else
-                hipLaunchKernelGGL(k_shade<false>, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
+                hipLaunchKernelGGL(k_shade<false>, dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
                                    n_out, ctx->d_L, (uint32_t)cap, prm->max_depth);
             HIPCHK(ctx, hipGetLastError());
             depths_run = it + 1;
