@@ -728,3 +728,91 @@ def test_coplanar_rays_divergence_is_bounded(gpu, mesh20k, mesh20k_oracle, ra):
                 m /= np.linalg.norm(m)
                 worst = min(worst, abs(float(m @ d[:, k].astype(np.float64))))
             assert worst < 1e-4, (k, ig[k], ic[k], tg[k], tc[k], worst)
+
+
+def test_shared_edge_and_duplicate_ties(gpu, ra, orc):
+    """Distance ties the fast tree (single-triangle leaves in surface-area order) has to settle through the
+    per-slot tie rank alone. (a) A flat sheet with dyadic coordinates, rays aimed straight at edge midpoints and
+    at vertices: the two (up to six) triangles sharing the edge (vertex) are hit at exactly the same t; where the
+    reference's median splits put them in different leaves the LATER leaf wins (KDTree.cpp:319-320), inside one
+    leaf the EARLIER triangle (:305). (b) Two copies of a bumpy sheet (two objects, identical vertices): every hit
+    ties with its twin, which the reference's build always puts in the same leaf."""
+    g = 12
+    xs = np.arange(g + 1, dtype=np.float64) / 8.0 - 0.75
+    vx, vy = np.meshgrid(xs, xs, indexing="ij")
+    idx = lambda i, j: i * (g + 1) + j
+    f = []
+    for i in range(g):
+        for j in range(g):
+            f.append((idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)))
+            f.append((idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)))
+    f = np.array(f, np.int64)
+    T = len(f)
+    ob = lambda c: meshgen._obj(ra.OBJ_DIFFUSE, c, has_vn=0)
+
+    # (a) flat sheet, rays at edge midpoints and vertices
+    v = np.stack([vx.ravel(), vy.ravel(), np.full((g + 1) ** 2, 0.25)], axis=1)
+    s = ra.HostScene.from_arrays(v.astype(np.float32), f.astype(np.uint32), np.zeros(T, np.int32),
+                                 np.array([ob((0.7, 0.7, 0.3))], ra.OBJECT_DTYPE), None)
+    S = orc.OracleScene(s.raw())
+    gpu.upload(s.describe())
+    pts = [v[1:-1]]  # vertices (the corners of the sheet included: they tie too, with fewer triangles)
+    for a_, b_ in ((0, 1), (1, 2), (2, 0)):
+        pts.append(0.5 * (v[f[:, a_]] + v[f[:, b_]]))  # edge midpoints: exact in fp32 (multiples of 1/16)
+    p = np.concatenate(pts).T
+    o = np.concatenate([p + np.array([[0.0], [0.0], [1.0]]), p + np.array([[0.0], [0.0], [-0.5]])], axis=1).astype(np.float32)
+    d = np.concatenate([np.tile([[0.0], [0.0], [-1.0]], p.shape[1]), np.tile([[0.0], [0.0], [1.0]], p.shape[1])], axis=1).astype(np.float32)
+    aux = ra.pack_ids(np.full(o.shape[1], -1), np.full(o.shape[1], -1))
+    tree = s.tree()
+    slot_of = np.empty(T, np.int64)
+    slot_of[tree["slot_tid"]] = np.arange(T)
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_NO_SELF, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = S.intersect(o, d, a, mode, threads=16)
+        assert (ig == ic).all() and (tg == tc).all(), "shared edges mode %d: %d ids differ" % (mode, (ig != ic).sum())
+        if mode == ra.MODE_UNCONDITIONAL:
+            assert (ic >= 0).all()
+            # the winners are neither always the first nor always the last of the tied triangles in slot order:
+            # both halves of the rule decide somewhere
+            px, py = o[0].astype(np.float64), o[1].astype(np.float64)
+            first = last = 0
+            for k in range(0, o.shape[1], 7):
+                tv = v[f]  # [T, 3, 3]
+                inside = np.ones(T, bool)
+                for e in range(3):
+                    ax, ay = tv[:, e, 0], tv[:, e, 1]
+                    bx, by = tv[:, (e + 1) % 3, 0], tv[:, (e + 1) % 3, 1]
+                    inside &= (bx - ax) * (py[k] - ay) - (by - ay) * (px[k] - ax) >= 0
+                tied = np.nonzero(inside)[0]
+                if len(tied) < 2:
+                    continue
+                sl = slot_of[tied]
+                first += int(slot_of[ic[k]] == sl.min())
+                last += int(slot_of[ic[k]] == sl.max())
+            assert first > 10 and last > 10, (first, last)
+    S.close()
+    s.close()
+
+    # (b) two copies of a bumpy sheet
+    v = np.stack([vx.ravel(), vy.ravel(), 0.125 * ((np.arange((g + 1) ** 2) * 7) % 5) / 4.0], axis=1)
+    verts = np.concatenate([v, v]).astype(np.float32)
+    tris = np.concatenate([f, f + len(v)]).astype(np.uint32)
+    tri_obj = np.concatenate([np.zeros(T, np.int32), np.ones(T, np.int32)])
+    s = ra.HostScene.from_arrays(verts, tris, tri_obj, np.array([ob((0.7, 0.7, 0.3)), ob((0.3, 0.7, 0.7))], ra.OBJECT_DTYPE), None)
+    S = orc.OracleScene(s.raw())
+    gpu.upload(s.describe())
+    n = 200000
+    rng = np.random.default_rng(5)
+    o = np.stack([rng.uniform(-0.9, 0.9, n), rng.uniform(-0.9, 0.9, n), rng.uniform(0.6, 1.5, n) * rng.choice([-1, 1], n)])
+    tgt = np.stack([rng.uniform(-0.7, 0.7, n), rng.uniform(-0.7, 0.7, n), np.full(n, 0.06)])
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=0, keepdims=True)
+    o, d = o.astype(np.float32), d.astype(np.float32)
+    aux = ra.pack_ids(np.full(n, -1), np.full(n, -1))
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_NO_SELF, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = S.intersect(o, d, a, mode, threads=16)
+        assert (ig == ic).all() and (tg == tc).all(), "duplicate sheets mode %d: %d ids differ" % (mode, (ig != ic).sum())
+        assert (ic >= 0).mean() > 0.5
+    S.close()
+    s.close()
