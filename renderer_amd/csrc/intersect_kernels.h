@@ -455,6 +455,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         }
     }
     } else {
+    // ---- the exact kernels (the reference tree, every box decided as the reference decides it): while-while ---------
     for (;;) {
         // ---- refill: lanes without a ray take the next rays of the wave's pool ---------------------
         const unsigned long long need = __ballot(!active);
@@ -502,11 +503,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 pre2 = ray_pairs(o, d, pre);
                 float lb;
                 const int code = slab_classify(root_lo, root_hi, box_is_flat(root_lo, root_hi), o, pre, lb);
-                if (FAST) {
-                    if (COUNT) au.box++;
-                    if (pre.fast && code != BOX_MISS) enter(__float_as_int(root_lo.w));
-                } else if (resolve(root_lo, root_hi, code, lb))
-                    enter(__float_as_int(root_lo.w));
+                if (resolve(root_lo, root_hi, code, lb)) enter(__float_as_int(root_lo.w));
             }
             pool_next += take;
         }
@@ -530,20 +527,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             const int cl = slab_classify_pair(P.la, P.lb, pre2, pre, lbl);
             const int cr = slab_classify_pair(P.ra, P.rb, pre2, pre, lbr);
             bool vl = cl == BOX_HIT, vr = cr == BOX_HIT;
-            if (FAST) {  // conservative: only a proven miss is skipped
-                vl = cl != BOX_MISS;
-                vr = cr != BOX_MISS;
-                if (COUNT) au.box += 2;
-                // A ray whose margin is wide (a nearly axis-parallel direction: |1/d| ~ 1e9) can prove
-                // almost no miss and would walk the whole tree: after FAST_AMBIGUOUS_BUDGET unproven
-                // boxes it is given up and left to the exact kernel (slot -2 tells k_verify).
-                unproven += (cl == BOX_AMBIGUOUS) + (cr == BOX_AMBIGUOUS);
-                if (unproven > FAST_AMBIGUOUS_BUDGET) {
-                    vl = vr = false;
-                    sp = 0;
-                    best_slot = -2;
-                }
-            } else if (COUNT || !pre.fast || cl == BOX_AMBIGUOUS || cr == BOX_AMBIGUOUS) {
+            if (COUNT || !pre.fast || cl == BOX_AMBIGUOUS || cr == BOX_AMBIGUOUS) {
                 vl = resolve(pair_lo(P.la, P.lb), pair_hi(P.la, P.lb), cl, lbl);
                 vr = resolve(pair_lo(P.ra, P.rb), pair_hi(P.ra, P.rb), cr, lbr);
             }
@@ -623,13 +607,11 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         if (ANYHIT) {
             if (active && !has) {
                 vis_out[idx] = occluded ? 0 : 1;
-                // FAST: the occluder's slot, -1 for "nothing in the superset" (final), -2 for a ray given up
-                if (FAST) id_out[idx] = best_slot;
                 active = false;
             }
         } else if (active && !has) {
             t_out[idx] = best_slot >= 0 ? best : -1.f;
-            if (SLOT_OUT || FAST)
+            if (SLOT_OUT)
                 id_out[idx] = best_slot;
             else
                 id_out[idx] = best_slot >= 0 ? __float_as_int(sc.vns[best_slot].n1.w) : -1;
