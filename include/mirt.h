@@ -206,11 +206,10 @@ uint64_t mirt_scene_serial(const MirtContext* ctx);
  * t_out: float[n]; tid_out: int32[n] global triangle id or -1. Host pointers.                */
 int mirt_intersect(MirtContext* ctx, const float* origins, const float* directions,
                    const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out);
-/* Same with DEVICE pointers; asynchronous on `stream` (a hipStream_t, NULL = context stream). Two first-use
- * exceptions synchronise the stream once: a batch larger than any before (a list buffer grows), and, in modes
- * 0 / 1, the first batch of >= 2^18 rays on a scene: both traversal routes are run three times each, alternating, on
- * (at most) the first 4 Mi rays of the batch and timed, and the one with the smaller median is kept for that scene and
- * mode (the answers are the same either way; MIRT_FAST_ALL_MODES=0/1 in the environment fixes the choice instead).  */
+/* Same with DEVICE pointers; asynchronous on `stream` (a hipStream_t, NULL = context stream). One first-use
+ * exception synchronises the stream once: a batch larger than any before (a list buffer grows). Every mode takes
+ * the same route on a scene (the fast tree when the scene has one; MIRT_FAST_ALL_MODES=0 in the environment sends
+ * modes 0 / 1 over the reference tree instead, for A/B runs; the answers are the same either way).            */
 int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* directions,
                        const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out,
                        void* stream);
@@ -220,9 +219,7 @@ int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* dire
  * memory (the ray-queue words, the list of rays handed to the exact re-run, the traversal-stack levels beyond the
  * LDS share) live in ONE static device array of 48 MiB + 256 B that every GPU the library runs on holds until the
  * process ends. Limits: n <= MIRT_NOALLOC_MAX_RAYS per call (MIRT_E_LIMIT beyond it); the persistent grid is cut
- * down until its deep stack levels fit 32 MiB (same answers, fewer waves on very deep trees). Modes 0 / 1 take
- * the route an earlier mirt_intersect_dev call settled on for the scene, else the reference tree alone (no timing
- * here). Every call on a GPU shares that GPU's array (all contexts on it too): calls that overlap on one GPU RACE -
+ * down until its deep stack levels fit 32 MiB (same answers, fewer waves on very deep trees). Every call on a GPU shares that GPU's array (all contexts on it too): calls that overlap on one GPU RACE -
  * serialise them (one stream, or events). Results are bit-identical to mirt_intersect_dev's.              */
 #define MIRT_NOALLOC_MAX_RAYS (4u << 20)
 int mirt_intersect_noalloc_dev(MirtContext* ctx, const float* origins, const float* directions,

@@ -53,18 +53,7 @@ struct MirtContext {
     float* d_texels = nullptr;
     DevBump* d_bumps = nullptr;
     bool has_bump = false;
-    bool fast_all_modes = false;    // modes 0 / 1 through the fast tree too (large scenes)
-    // modes 0 / 1 on smaller scenes: which path is faster depends on the rays (camera inside or outside the
-    // geometry ...), so the first large call of a mode runs BOTH paths, times them and keeps the faster one for the
-    // scene (three extra launches of each and one stream synchronisation, once per scene and mode; both paths return
-    // the same answers; tune_routes). state: 0 untimed, 3 decided.
-    struct PathTune {
-        int state = 0;
-        bool use_fast = false;
-        double exact_ns_per_ray = 0, fast_ns_per_ray = 0;
-        hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    } tune[2];
-    bool tune_modes = true;
+    bool fast_all_modes = true;     // modes 0 / 1 through the fast tree too (MIRT_FAST_ALL_MODES=0: the reference tree)
     float* d_light_area = nullptr;
     int* d_light_slot = nullptr;
     int block = 256;
@@ -302,11 +291,6 @@ int mirt_destroy(MirtContext* ctx) {
     hipFree(ctx->d_wq2);
     hipFree(ctx->d_counters);
     hipFree(ctx->d_queue);
-    for (auto& t : ctx->tune)
-        for (hipEvent_t& e : t.ev) {
-            if (e) hipEventDestroy(e);
-            e = nullptr;
-        }
     hipFree(ctx->d_fb_list);
     hipFree(ctx->d_vis_slot);
     if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
@@ -988,16 +972,12 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     // (a scene outside the classifier's model, fast_ok = 0, would have every ray skipped by the fast walk, listed
     // by k_verify and re-run exactly: it stays on the reference tree alone)
     ctx->fast_tree = use_fast && fast_ok;
-    // Modes 0 / 1 (coherent camera rays, as a rule): on the Cornell scene the reference tree alone is faster
-    // (0.89 vs 0.98 ms per 4 Mi rays: verify + re-run cost more than the shorter walk saves), on the 1 M-triangle
-    // scene the fast tree is (1.99 -> 1.57 ms): the walk is what waits for memory there.
-    ctx->fast_all_modes = N >= 100000;
-    ctx->tune_modes = true;
-    if (const char* e = getenv("MIRT_FAST_ALL_MODES")) {  // A/B switch: forces either way, no timing
-        ctx->fast_all_modes = atoi(e) != 0;
-        ctx->tune_modes = false;
-    }
-    for (auto& t : ctx->tune) t.state = 0, t.use_fast = false;
+    // Modes 0 / 1 (coherent camera rays, as a rule) take the fast route as well: 4 Mi camera rays at 1024^2 take
+    // 0.40 ms against 0.66 .. 1.54 ms on the reference tree on every scene of Data/ (scripts/camtest.py). Until the
+    // fast tree's leaves became single triangles the two routes were close on small scenes and the first large call
+    // timed both; that timing, its events and its stream synchronisation are gone.
+    ctx->fast_all_modes = true;
+    if (const char* e = getenv("MIRT_FAST_ALL_MODES")) ctx->fast_all_modes = atoi(e) != 0;  // A/B switch
     ctx->sc.vols = ctx->d_vols;
     ctx->sc.n_vols = n_obj_trees;
     if (!lights.empty()) {
@@ -1249,58 +1229,6 @@ static int route_fast(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, in
     return rc;
 }
 
-// Modes 0 / 1 on scenes below fast_all_modes' size: which route is faster depends on the rays, so the first call of
-// a mode with >= 2^18 rays on a scene runs BOTH routes three times each, alternating, times them with events and keeps
-// the one with the smaller median for that scene and mode (both return the same answers; the caller's buffers hold
-// the last run's). Synchronises the stream and creates events: never reached from mirt_intersect_noalloc_dev.
-template <bool SLOT_OUT>
-static int tune_routes(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, int mode, const float* O, const float* D,
-                       const int* aux, uint32_t n, uint32_t stride, float* t_out, int* id_out, uint32_t* qwords) {
-    MirtContext::PathTune& T = ctx->tune[mode];
-    constexpr int REPS = 3;
-    for (hipEvent_t& e : T.ev)
-        if (!e && hipEventCreate(&e) != hipSuccess) {
-            T.state = 3;  // no events: stay on the reference tree
-            T.use_fast = false;
-            return route_exact<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, n, stride, t_out, id_out, nullptr, qwords);
-        }
-    // timed on a prefix of the batch (the wavefront path tracer's camera pass can hold 10^8 rays); the whole batch
-    // then takes the route chosen
-    const uint32_t nt = std::min<uint32_t>(n, 1u << 22);
-    HIPCHK(ctx, hipEventRecord(T.ev[0], st));
-    for (int r = 0; r < REPS; r++) {
-        HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
-        int rc = route_exact<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, nt, stride, t_out, id_out, nullptr, qwords);
-        if (rc != MIRT_OK) return rc;
-        HIPCHK(ctx, hipEventRecord(T.ev[2 * r + 1], st));
-        HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
-        rc = route_fast<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, nt, stride, t_out, id_out, nullptr, qwords);
-        if (rc != MIRT_OK) return rc;
-        HIPCHK(ctx, hipEventRecord(T.ev[2 * r + 2], st));
-    }
-    HIPCHK(ctx, hipEventSynchronize(T.ev[2 * REPS]));
-    float ex[REPS], fa[REPS];
-    bool ok = true;
-    for (int r = 0; r < REPS; r++)
-        ok = ok && hipEventElapsedTime(&ex[r], T.ev[2 * r], T.ev[2 * r + 1]) == hipSuccess &&
-             hipEventElapsedTime(&fa[r], T.ev[2 * r + 1], T.ev[2 * r + 2]) == hipSuccess;
-    if (ok) {
-        std::sort(ex, ex + REPS);
-        std::sort(fa, fa + REPS);
-        T.exact_ns_per_ray = (double)ex[REPS / 2] * 1e6 / nt;
-        T.fast_ns_per_ray = (double)fa[REPS / 2] * 1e6 / nt;
-        T.use_fast = fa[REPS / 2] < 0.97f * ex[REPS / 2];
-        if (getenv("MIRT_DEBUG_TUNE"))
-            fprintf(stderr, "[mirt] mode %d: reference tree %.3f ns/ray, fast tree %.3f ns/ray (medians of %d) -> %s\n", mode,
-                    T.exact_ns_per_ray, T.fast_ns_per_ray, REPS, T.use_fast ? "fast tree" : "reference tree");
-    }
-    T.state = 3;
-    if (nt == n) return MIRT_OK;  // (the last timed run was the fast route over the whole batch)
-    HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
-    if (T.use_fast) return route_fast<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, n, stride, t_out, id_out, nullptr, qwords);
-    return route_exact<false, SLOT_OUT>(ctx, lb, st, mode, O, D, aux, n, stride, t_out, id_out, nullptr, qwords);
-}
-
 // Closest hit of n rays (n_ptr != nullptr: the count is read on the device, at most n). `qwords`: three zeroed
 // words owned by this call (queue head of the fast launch, list length, queue head of the exact launch).
 // exact_only: the reference tree alone (the audit entry point, and scenes without a fast tree).
@@ -1312,30 +1240,17 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
                             const uint32_t* n_ptr = nullptr, uint32_t* qwords = nullptr, bool exact_only = false,
                             const LaunchBufs* bufs = nullptr) {
     if (n == 0) return MIRT_OK;
-    // the fast route serves the predicate mode (incoherent rays), on large scenes the other two as well
-    // (ctx->fast_all_modes, set at upload), and on the rest whichever route the first large call showed faster
-    bool use_fast = !exact_only && ctx->fast_tree && (mode == MIRT_MODE_NO_SELF || ctx->fast_all_modes);
-    bool tune = false;
-    if (!exact_only && ctx->fast_tree && !ctx->fast_all_modes && ctx->tune_modes &&
-        (mode == MIRT_MODE_UNCONDITIONAL || mode == MIRT_MODE_LAST_TID)) {
-        MirtContext::PathTune& T = ctx->tune[mode];
-        if (T.state == 3)
-            use_fast = T.use_fast;  // (the instrumented calls follow the choice, they never make it)
-        else
-            tune = !COUNT && !n_ptr && !bufs && n >= (1u << 18);
-    }
+    // the fast route serves every mode of a scene that has a fast tree (ctx->fast_all_modes: A/B switch for modes 0 / 1)
+    const bool use_fast = !exact_only && ctx->fast_tree && (mode == MIRT_MODE_NO_SELF || ctx->fast_all_modes);
     LaunchBufs own;
     if (!bufs) {
-        const int rc = context_bufs(ctx, st, n, use_fast || tune, &own);
+        const int rc = context_bufs(ctx, st, n, use_fast, &own);
         if (rc != MIRT_OK) return rc;
         bufs = &own;
     }
     if (!qwords) {
         qwords = ctx->d_queue;
         HIPCHK(ctx, hipMemsetAsync(qwords, 0, 3 * sizeof(uint32_t), st));
-    }
-    if constexpr (!COUNT) {
-        if (tune) return tune_routes<SLOT_OUT>(ctx, *bufs, st, mode, O, D, aux, n, stride, t_out, id_out, qwords);
     }
     if (!use_fast) return route_exact<COUNT, SLOT_OUT>(ctx, *bufs, st, mode, O, D, aux, n, stride, t_out, id_out, n_ptr, qwords);
     return route_fast<COUNT, SLOT_OUT>(ctx, *bufs, st, mode, O, D, aux, n, stride, t_out, id_out, n_ptr, qwords);

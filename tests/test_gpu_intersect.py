@@ -189,10 +189,11 @@ def test_large_batch_properties(cornell_dev, cornell, ra):
 
 def test_counts_match_ordered_restatement(cornell_dev, cornell, cornell_oracle, ra):
     """The instrumented launches' box / triangle test counts agree with the CPU restatement of the same
-    traversal (they feed the algorithmic-bytes figure of bench.py): mode 0 walks the reference tree
-    near-first with pruning, mode 2 walks the fast tree, then the winner's chain of reference boxes. Not
-    bit-equal: the kernel orders children by slab distances computed with per-ray reciprocals, enters the
-    rare boxes its classifier cannot prove, and its conservative test differs in the last digits."""
+    traversal (they feed the algorithmic-bytes figure of bench.py): every mode walks the fast tree, then the
+    winner's chain of reference boxes (mirt_intersect_count_dev against the oracle's intersect_fast); the audit
+    entry point walks the reference tree near-first with pruning (against intersect_ordered). Not bit-equal: the
+    kernel orders children by slab distances computed with per-ray reciprocals, enters the rare boxes its
+    classifier cannot prove, and its conservative test differs in the last digits."""
     import torch
 
     n = 50000
@@ -205,14 +206,16 @@ def test_counts_match_ordered_restatement(cornell_dev, cornell, cornell_oracle, 
     for mode in (0, 2):
         nb, nt = cornell_dev.intersect_count_dev(to.data_ptr(), do_.data_ptr(), ta.data_ptr(), n, mode,
                                                  tt.data_ptr(), ti.data_ptr())
-        if mode == 0:
-            t2, i2, cb, ct = cornell_oracle.intersect_ordered(o, d, aux, mode)
-        else:
-            t2, i2, cb, ct = cornell_oracle.intersect_fast(ft, o, d, aux, mode)
+        t2, i2, cb, ct = cornell_oracle.intersect_fast(ft, o, d, aux, mode)
         assert abs(nb - cb) / cb < 0.03 and abs(nt - ct) / ct < 0.03, (mode, nb, cb, nt, ct)
         assert np.array_equal(ti.cpu().numpy(), i2) and np.array_equal(tt.cpu().numpy(), t2)
         rb, rt = cornell_oracle.ref_counts(o[:, :5000], d[:, :5000], aux[:5000], mode)
         assert nb / n < rb / 5000 and nt / n < rt / 5000
+        au = cornell_dev.intersect_audit_dev(to.data_ptr(), do_.data_ptr(), ta.data_ptr(), n, mode, tt.data_ptr(),
+                                             ti.data_ptr())
+        t3, i3, cb3, ct3 = cornell_oracle.intersect_ordered(o, d, aux, mode)
+        assert abs(au["box"] - cb3) / cb3 < 0.03 and abs(au["tri"] - ct3) / ct3 < 0.03, (mode, au, cb3, ct3)
+        assert np.array_equal(ti.cpu().numpy(), i3) and np.array_equal(tt.cpu().numpy(), t3)
 
 
 def _adversarial_rays(scene, n, seed):
@@ -268,10 +271,12 @@ def test_fast_path_fallbacks(gpu, cornell, cornell_oracle, mesh20k, mesh20k_orac
 
 
 def test_fast_path_other_modes(gpu, cornell, cornell_oracle, mesh20k, mesh20k_oracle, ra, monkeypatch):
-    """Large scenes send modes 0 and 1 through the fast tree as well (k_rerun<…, MODE> answers the rejected
-    rays); forced on here for the small scenes, against the oracle bit for bit, adversarial rays included"""
-    monkeypatch.setenv("MIRT_FAST_ALL_MODES", "1")
-    for scene, S in ((cornell, cornell_oracle), (mesh20k, mesh20k_oracle)):
+    """Modes 0 and 1 go through the fast tree as well (k_rerun<…, MODE> answers the rejected rays), or, with
+    MIRT_FAST_ALL_MODES=0, over the reference tree alone (the exact kernels): both against the oracle bit for
+    bit, adversarial rays included"""
+    for scene, S, route in ((cornell, cornell_oracle, "1"), (mesh20k, mesh20k_oracle, "1"), (cornell, cornell_oracle, "0"),
+                            (mesh20k, mesh20k_oracle, "0")):
+        monkeypatch.setenv("MIRT_FAST_ALL_MODES", route)  # (read at upload)
         gpu.upload(scene.describe())
         n = 100000
         o, d = _adversarial_rays(scene, n, 17)
