@@ -125,7 +125,7 @@ def closest_hit_section(workload, args, rank, world, local, barrier, tstream, wa
         if events is not None:
             events[2].record(tstream)
 
-    # (at least one untimed pass: the first large call of modes 0 / 1 on a scene times both traversal routes once)
+    # (at least one untimed pass: the first large call on a scene grows the library's list buffer once)
     for _ in range(max(args.warmup, 1)):
         step()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
@@ -137,7 +137,7 @@ def closest_hit_section(workload, args, rank, world, local, barrier, tstream, wa
     elapsed = time.perf_counter() - t0
     hit_rate = float(((pi_ >= 0).sum() + (si_ >= 0).sum()).item()) / n_rays  # of the timed passes' own answers
     # ---- algorithmic work of the route that was timed: the product path instrumented (fast tree + verified
-    # chains + re-run in mode 2; whichever route modes 0 / 1 settled on), never timed.
+    # chains + re-run, in every mode), never timed.
     ct = torch.empty(max(n_pri, n_sec), dtype=torch.float32, device="cuda")
     ci = torch.empty(max(n_pri, n_sec), dtype=torch.int32, device="cuda")
     pb, ptr_ = dev.intersect_count_dev(po.data_ptr(), pd.data_ptr(), None, n_pri, ra.MODE_UNCONDITIONAL,
