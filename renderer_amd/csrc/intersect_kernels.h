@@ -202,6 +202,11 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
     int a = 0;
     float best = -1.f, thr = INF;  // thr: entry distances beyond it cannot beat the closest hit (prune())
+    // FAST: entry distance of the box being visited. A fast-tree leaf is one triangle's own box, and the reference's
+    // t = orthoDist / (n.d) of a sliver (an fp32 plane normal off by 1e-3) or of a grazing hit can lie IN FRONT of that
+    // box by more than the prune slack; pruning against such a t would skip the triangle's twin in a tie, or a triangle
+    // whose own t is as far off. accept() therefore prunes against max(t, entry distance of the accepted triangle's box).
+    float cur_lb = 0.f;
     int best_slot = -1, link = 0;
     uint32_t sp = 0;  // stack depth as the BYTE offset of the next free LDS level (level * blockDim * 8)
     int leaf_pos = 0, leaf_end = 0;  // triangles still to test in the current leaf
@@ -231,9 +236,10 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         if (COUNT && box_test(lo, hi, o, d).hit != (code == BOX_HIT)) au.bad++;
         return code == BOX_HIT;
     };
-    auto enter = [&](int lk) {  // start visiting child link lk
+    auto enter = [&](int lk, float lb = 0.f) {  // start visiting child link lk, whose box the ray enters at lb
         link = lk;
         has = true;
+        if (FAST) cur_lb = lb;
         const uint32_t v = ~(uint32_t)lk;  // leaf fields; meaningless (and unused) for an inner node
         leaf_pos = (int)(v & 0xFFFFFFu);
         leaf_end = leaf_pos + (int)(v >> 24);
@@ -251,7 +257,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 packed = *stk_deep((sp - lds_bytes) >> level_shift);
             const uint2 e = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
             if (__uint_as_float(e.y) > thr) continue;
-            enter((int)e.x);
+            enter((int)e.x, __uint_as_float(e.y));
             break;
         }
     };
@@ -264,7 +270,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         }
         best = t;
         best_slot = s;
-        thr = t * 1.0001f + 1e-5f;
+        thr = (FAST ? fmaxf(t, cur_lb) : t) * 1.0001f + 1e-5f;
     };
 
     // The fast-tree kernels (incoherent rays, deep walks) take the vote loop; the exact kernels (camera rays on small
@@ -389,7 +395,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                     sp += level_bytes;
                 }
                 if (vl | vr)
-                    enter(pick_l ? kl : kr);
+                    enter(pick_l ? kl : kr, pick_l ? lbl : lbr);
                 else
                     pop();
             }
