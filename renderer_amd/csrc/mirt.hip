@@ -394,6 +394,36 @@ struct FastTree {
 };
 
 // slot_box(slot, mn, mx) widens mn / mx by the triangle in that device slot.
+// The fast tree's box of one triangle: the box of its corners, widened by how far outside the triangle the
+// reference's edge-sign test (KDTree.cpp:267-289) can still accept a ray. Each sign d.(l_i x r_i) carries a rounding
+// error of <= 16 eps |d||l_i||r_i|, i.e. the ray may pass an edge's line on the wrong side by ~16 eps |r_i| (for a ray
+// not nearly parallel to that edge); where two edges meet at an angle theta the accepted region reaches beyond the
+// corner by that over sin(theta). A well-shaped triangle gets ~1e-5 of the scene's size, a needle (found by
+// tests/test_gpu_fuzz.py: a sliver 1e-4 wide accepted 2e-4 beyond its tip) up to the whole reference leaf box, to
+// which build_fast_tree clips. bound: largest coordinate magnitude of the scene; rays are assumed to start within
+// four times that.
+static void tri_fast_box(const float* p, float bound, float* mn, float* mx) {
+    double sin_min = 1.0;
+    for (int c = 0; c < 3; c++) {
+        const float* a = p + 3 * c;
+        const float* b = p + 3 * ((c + 1) % 3);
+        const float* e = p + 3 * ((c + 2) % 3);
+        const double u[3] = {(double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2]};
+        const double w[3] = {(double)e[0] - a[0], (double)e[1] - a[1], (double)e[2] - a[2]};
+        const double cr[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0]};
+        const double nu = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), nw = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        const double sn = nu > 0 && nw > 0 ? std::sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]) / (nu * nw) : 0.0;
+        sin_min = std::min(sin_min, sn);
+    }
+    const double pad_d = 64.0 * 5.9604644775390625e-08 * 4.0 * (double)bound / std::max(sin_min, 1e-12);
+    const float pad = (float)std::min(pad_d, 8.0 * (double)bound) * 1.0000002f;
+    for (int v = 0; v < 3; v++)
+        for (int k = 0; k < 3; k++) {
+            mn[k] = std::min(mn[k], p[3 * v + k] - pad);
+            mx[k] = std::max(mx[k], p[3 * v + k] + pad);
+        }
+}
+
 #ifndef MIRT_SAH_BINS
 #define MIRT_SAH_BINS 16
 #endif
@@ -411,6 +441,12 @@ static void build_fast_tree(const TreeView& ref, FastTree& ft, const std::functi
                 l.e = t + 1;
                 for (int k = 0; k < 3; k++) l.mn[k] = INFINITY, l.mx[k] = -INFINITY;
                 slot_box(t, l.mn, l.mx);
+                // never larger than the reference leaf's own box: the reference tests the triangle only for rays
+                // that pass that box (k_verify checks it), so nothing outside it can matter
+                for (int k = 0; k < 3; k++) {
+                    l.mn[k] = std::max(l.mn[k], ref.mn[3 * i + k]);
+                    l.mx[k] = std::min(l.mx[k], ref.mx[3 * i + k]);
+                }
                 for (int k = 0; k < 3; k++) l.c[k] = 0.5f * (l.mn[k] + l.mx[k]);
                 leaves.push_back(l);
             }
@@ -802,13 +838,9 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         }
         if (use_fast) {
             FastTree ft;
+            const float bmax = std::max(bound[0], std::max(bound[1], bound[2]));
             build_fast_tree(main_tree, ft, [&](int slot, float* mn, float* mx) {
-                const float* p = s->tri_pos + 9 * (size_t)s->slot_tid[main_src[slot]];
-                for (int v = 0; v < 3; v++)
-                    for (int k = 0; k < 3; k++) {
-                        mn[k] = std::min(mn[k], p[3 * v + k]);
-                        mx[k] = std::max(mx[k], p[3 * v + k]);
-                    }
+                tri_fast_box(s->tri_pos + 9 * (size_t)s->slot_tid[main_src[slot]], bmax, mn, mx);
             });
             if (ft.right.empty()) {
                 use_fast = false;
@@ -1349,13 +1381,11 @@ int mirt_fast_tree(const MirtSceneDesc* s, int32_t capacity_nodes, int32_t* n_no
     if (s->n_tris > 0 && (!s->tri_pos || !s->slot_tid)) return MIRT_E_INVALID;
     FastTree ft;
     const std::vector<int> src = seam_order(view);  // device slot -> position in the reference's slot order
+    float bmax = 0.f;
+    for (int c = 0; c < 3; c++)
+        for (float x : {s->node_min[c], s->node_max[c]}) bmax = std::max(bmax, std::fabs(x));
     build_fast_tree(view, ft, [&](int slot, float* mn, float* mx) {
-        const float* p = s->tri_pos + 9 * (size_t)s->slot_tid[src[slot]];
-        for (int v = 0; v < 3; v++)
-            for (int k = 0; k < 3; k++) {
-                mn[k] = std::min(mn[k], p[3 * v + k]);
-                mx[k] = std::max(mx[k], p[3 * v + k]);
-            }
+        tri_fast_box(s->tri_pos + 9 * (size_t)s->slot_tid[src[slot]], bmax, mn, mx);
     });
     const int32_t n = (int32_t)ft.right.size();
     *n_nodes_out = n;
