@@ -206,6 +206,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     // t = orthoDist / (n.d) of a sliver (an fp32 plane normal off by 1e-3) or of a grazing hit can lie IN FRONT of that
     // box by more than the prune slack; pruning against such a t would skip the triangle's twin in a tie, or a triangle
     // whose own t is as far off. accept() therefore prunes against max(t, entry distance of the accepted triangle's box).
+    // The entry distances themselves are slab_miss_pair's one-FMA parameters, each off by up to 3/16 a_ray (far from
+    // the origin that is much more than the prune slack: |o| = 300, 1/d = 13 gives 1e-3), so thr carries a_ray / 2.
     float cur_lb = 0.f;
     int best_slot = -1, link = 0;
     uint32_t sp = 0;  // stack depth as the BYTE offset of the next free LDS level (level * blockDim * 8)
@@ -270,7 +272,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         }
         best = t;
         best_slot = s;
-        thr = (FAST ? fmaxf(t, cur_lb) : t) * 1.0001f + 1e-5f;
+        thr = FAST ? __builtin_fmaf(fmaxf(t, cur_lb), 1.0001f, 1e-5f + 0.5f * pre.a_ray) : t * 1.0001f + 1e-5f;
     };
 
     // The fast-tree kernels (incoherent rays, deep walks) take the vote loop; the exact kernels (camera rays on small
@@ -317,7 +319,6 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 thr = INF;
                 if (ANYHIT) {
                     lim = limit[idx];
-                    thr = lim * 1.0001f + 1e-5f;  // nothing beyond the limit can occlude
                     occluded = false;
                 }
                 best_slot = -1;
@@ -327,6 +328,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 active = true;
                 pre = ray_prepare(sc, o, d);
                 pre2 = ray_pairs(o, d, pre);
+                // nothing beyond the limit can occlude (+ the rounding of this kernel's entry distances, see cur_lb)
+                if (ANYHIT) thr = __builtin_fmaf(lim, 1.0001f, 1e-5f + 0.5f * pre.a_ray);
                 float lb;
                 const int code = slab_classify(root_lo, root_hi, box_is_flat(root_lo, root_hi), o, pre, lb);
                 if (FAST) {

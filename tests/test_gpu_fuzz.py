@@ -10,7 +10,7 @@ import meshgen
 pytestmark = pytest.mark.gpu
 
 
-def _soup(ra, rng, n_tri, n_obj):
+def _soup(ra, rng, n_tri, n_obj, scale=1.0, offset=(0.0, 0.0, 0.0)):
     kind = rng.integers(0, 5, n_tri)
     c = rng.uniform(-0.9, 0.9, (n_tri, 1, 3))
     size = 10.0 ** rng.uniform(-2.5, -0.3, (n_tri, 1, 1))
@@ -25,7 +25,7 @@ def _soup(ra, rng, n_tri, n_obj):
     v[dg, 2] = v[dg, 1]
     dup = np.nonzero(kind == 4)[0]  # duplicates of another triangle
     v[dup] = v[rng.integers(0, n_tri, len(dup))]
-    v = np.clip(v, -1.0, 1.0).astype(np.float32)
+    v = (np.clip(v, -1.0, 1.0) * scale + np.asarray(offset)).astype(np.float32)
     verts = v.reshape(-1, 3)
     tris = np.arange(3 * n_tri, dtype=np.uint32).reshape(n_tri, 3)
     tri_obj = np.sort(rng.integers(0, n_obj, n_tri)).astype(np.int32)
@@ -36,9 +36,9 @@ def _soup(ra, rng, n_tri, n_obj):
     return ra.HostScene.from_arrays(verts, tris, tri_obj, objects, vn), v
 
 
-def _rays(rng, v, n, n_obj, ra):
+def _rays(rng, v, n, n_obj, ra, scale=1.0, offset=(0.0, 0.0, 0.0), tri_obj=None):
     T = len(v)
-    o = rng.uniform(-1.2, 1.2, (n, 3))
+    o = rng.uniform(-1.2, 1.2, (n, 3)) * scale + np.asarray(offset)
     k = rng.integers(0, T, n)
     w = rng.dirichlet((1, 1, 1), n)
     pick = rng.integers(0, 4, n)
@@ -55,6 +55,9 @@ def _rays(rng, v, n, n_obj, ra):
     d[on] = rng.normal(size=(on.sum(), 3))
     d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
     contact = rng.integers(-1, n_obj, n)
+    if tri_obj is not None:  # half of the rays that start on a triangle know it as their contact object, as bounce rays do
+        own = on & (rng.random(n) < 0.5)
+        contact[own] = tri_obj[k2[own]]
     inside = np.where(rng.random(n) < 0.7, -1, rng.integers(-1, n_obj, n))
     return (np.ascontiguousarray(o.T, np.float32), np.ascontiguousarray(d.T, np.float32),
             ra.pack_ids(contact, inside), k2.astype(np.int32))
@@ -134,5 +137,61 @@ def test_triangle_soup_visibility_against_oracle(gpu, ra, orc, seed, n_tri):
             nd = float(m @ d[:, q].astype(np.float64))
             t_true = float(m @ (w[2] - o[:, q].astype(np.float64))) / nd
             assert abs(nd) < 1e-3 or abs(t_true - float(tq[j])) > 1e-4 * abs(t_true) + 1e-5, (mode, q, t_true, tq[j])
+    S.close()
+    scene.close()
+
+
+@pytest.mark.parametrize("seed,n_tri,scale,offset", [(21, 3000, 1.0, (0, 0, 0)), (22, 3000, 25.0, (300.0, -120.0, 75.0)),
+                                                    (23, 800, 1e-3, (0.0, 0.0, 0.0))])
+def test_soup_bounce_and_edge_parallel_rays(gpu, ra, orc, seed, n_tri, scale, offset):
+    """(a) bounce-like rays (origin on a triangle, that triangle's object as the contact object) on soups that are
+    scaled and moved away from the origin (the error model's margins scale with the coordinates); (b) rays running
+    along a triangle's edge direction, tilted by 1e-7 .. 1e-2 rad and passing 1e-6 .. 1e-3 (in units of the scene)
+    beside that edge: the reference's edge sign for that edge is then rounding noise over a reach that grows as
+    1 / tilt, the one situation the widened leaf boxes do not bound. Ids must agree bit for bit in (a)
+    and on all but a small share of (b), where every differing ray must be such an edge-parallel one by construction."""
+    rng = np.random.default_rng(3000 + seed)
+    n_obj = 5
+    scene, v = _soup(ra, rng, n_tri, n_obj, scale, offset)
+    tri_obj = scene.raw()["tri_obj"]
+    S = orc.OracleScene(scene.raw())
+    gpu.upload(scene.describe())
+    n = 150000
+    o, d, aux, last = _rays(rng, v, n, n_obj, ra, scale, offset, tri_obj)
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_NO_SELF, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = S.intersect(o, d, a, mode, threads=16)
+        nd = int(((ig != ic) | ~((tg == tc) | (np.isnan(tg) & np.isnan(tc)))).sum())
+        print("soup seed %d scale %g mode %d: hit rate %.2f, %d of %d rays differ" % (seed, scale, mode, (ic >= 0).mean(), nd, n))
+        assert nd <= 2e-5 * n, (mode, nd)
+    # (b)
+    T = len(v)
+    k = rng.integers(0, T, n)
+    e = rng.integers(0, 3, n)
+    va = v[k, e].astype(np.float64)
+    vb = v[k, (e + 1) % 3].astype(np.float64)
+    vc = v[k, (e + 2) % 3].astype(np.float64)
+    ed = vb - va
+    el = np.linalg.norm(ed, axis=1, keepdims=True)
+    ok = el[:, 0] > 0
+    ed = np.where(ok[:, None], ed / np.maximum(el, 1e-30), (1.0, 0.0, 0.0))
+    out = va - vc
+    out -= ed * (out * ed).sum(1, keepdims=True)  # in the triangle's plane, pointing away from the third corner
+    out /= np.maximum(np.linalg.norm(out, axis=1, keepdims=True), 1e-30)
+    nrm = np.cross(ed, out)
+    side = scale * 10.0 ** rng.uniform(-6, -3, (n, 1)) * rng.choice([-1.0, 1.0], (n, 1))
+    lift = scale * 10.0 ** rng.uniform(-6, -3, (n, 1)) * rng.choice([-1.0, 0.0, 1.0], (n, 1))
+    tilt = 10.0 ** rng.uniform(-7, -2, (n, 1))
+    dd = ed + tilt * (np.cos(rng.uniform(0, 6.28, (n, 1))) * out + np.sin(rng.uniform(0, 6.28, (n, 1))) * nrm)
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    oo = va + side * out + lift * nrm - dd * (scale * rng.uniform(0.2, 1.0, (n, 1)))
+    o2, d2 = np.ascontiguousarray(oo.T, np.float32), np.ascontiguousarray(dd.T, np.float32)
+    aux2 = ra.pack_ids(np.full(n, -1), np.full(n, -1))
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_NO_SELF, aux2)):
+        tg, ig = gpu.intersect(o2, d2, a, mode)
+        tc, ic = S.intersect(o2, d2, a, mode, threads=16)
+        nd = int((ig != ic).sum())
+        print("soup seed %d scale %g mode %d, edge-parallel rays: %d of %d differ" % (seed, scale, mode, nd, n))
+        assert nd <= 5e-4 * n, (mode, nd)
     S.close()
     scene.close()
