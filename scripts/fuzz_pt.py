@@ -1,0 +1,46 @@
+"""One-off: path-traced images of random triangle soups (slivers, degenerate and duplicated triangles, random vertex
+normals; one emissive object), GPU against the CPU oracle at the same seed. usage: fuzz_pt.py first_seed n_seeds"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import renderer_amd as ra, orc
+from renderer_amd import meshgen
+import test_gpu_fuzz as F
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((np.clip(a, 0, 1) - np.clip(b, 0, 1)) ** 2)))
+
+dev = ra.Device(device=0)
+for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
+    rng = np.random.default_rng(seed)
+    n_tri = int(10 ** rng.uniform(1.5, 3.7))
+    n_obj = 6
+    scene, v = F._soup(ra, rng, n_tri, n_obj)
+    raw = scene.raw()
+    objs = raw["objects"].copy()
+    kinds = [ra.OBJ_EMISSIVE, ra.OBJ_DIFFUSE, ra.OBJ_GLOSSY, ra.OBJ_REFRACTIVE, ra.OBJ_PHONG, ra.OBJ_DIFFUSE]
+    for k in range(n_obj):
+        o = meshgen._obj(kinds[k], (8, 8, 8) if k == 0 else tuple(rng.uniform(0.3, 0.9, 3)), coeff=float(rng.uniform(2, 40)), ior=1.5,
+                         has_vn=int(rng.integers(0, 2)), color2=tuple(rng.uniform(0.1, 0.5, 3)))
+        objs[k] = np.array(o, ra.OBJECT_DTYPE)
+    scene.close()
+    scene = ra.HostScene.from_arrays(raw["verts"], raw["tris"], raw["tri_obj"], objs, raw["tri_vn"])
+    S = orc.OracleScene(scene.raw())
+    dev.upload(scene.describe())
+    cam = ra.make_camera(96, 96, 60, position=(0, 0, 3.2))
+    spp = 32
+    for integ in ("pt", "pttest"):
+        if integ == "pt":
+            g, st = dev.render_pt(cam, spp, seed=3)
+            c, nr = S.render(cam, spp, seed=3, threads=16)
+            c2, _ = S.render(cam, spp, seed=103, threads=16)
+        else:
+            g, st = dev.render_pttest(cam, spp, seed=3)
+            c, nr = S.render_pttest(cam, spp, seed=3, threads=16)[:2]
+            c2 = S.render_pttest(cam, spp, seed=103, threads=16)[0]
+        same, noise = rmse(g / spp, c / spp), rmse(c / spp, c2 / spp)
+        print("seed %d tris %d %s: same-seed rmse %.3g noise %.3g ratio %.3g | identical pixels %.3f | nan gpu %d cpu %d | rays gpu %d cpu %d | mean %s vs %s" % (
+            seed, n_tri, integ, same, noise, same / max(noise, 1e-30), (g == c).all(-1).mean(), int(np.isnan(g).sum()), int(np.isnan(c).sum()),
+            int(st.n_rays), nr, np.nanmean(g / spp, (0, 1)).round(4), np.nanmean(c / spp, (0, 1)).round(4)), flush=True)
+    S.close(); scene.close()
