@@ -45,7 +45,7 @@ namespace mirt {
 #define MIRT_RAY_CHUNK_COHERENT 256
 #endif
 #ifndef MIRT_RAY_CHUNK_INCOHERENT
-#define MIRT_RAY_CHUNK_INCOHERENT 128
+#define MIRT_RAY_CHUNK_INCOHERENT 256
 #endif
 #ifndef MIRT_RAY_CHUNK_MIN_RAYS
 #define MIRT_RAY_CHUNK_MIN_RAYS (1u << 20)
@@ -53,14 +53,19 @@ namespace mirt {
 #ifndef MIRT_LEAF_BATCH
 #define MIRT_LEAF_BATCH 8
 #endif
-// Rays a wave reserves per queue atomic. A wave refills idle lanes from its current chunk, so the chunk size is
-// also how far apart in the batch the rays of one wave lie: camera rays (modes 0 / 1, neighbours in the batch are
-// neighbours on the screen) gain from long chunks (4 Mi Cornell camera rays: 0.89 ms at 64, 0.66 at 128, 0.63 at
-// 256, 0.74 at 512), bounce rays barely (3.70 / 3.68 / 3.76 / 4.07 ms). Small launches keep 64 so that every wave
-// of the grid gets work.
+// Rays a wave reserves per queue atomic. Same-address atomics of the whole chip are served one per ~9 ns, so the
+// chunk size caps a launch at chunk / 9 ns (64 rays: 7 Grays/s, below what camera rays reach), and a wave that
+// waits for its atomic idles. In the fast-tree kernels the chunk is a pool in LDS that the four waves of a block
+// consume together in pieces of <= 64 rays (s_pool below), so the end of a launch is balanced at that granularity
+// whatever the chunk; 4 Mi Cornell camera rays: 0.41 ms with private 256-ray chunks, 0.36 with a static round-robin
+// (no atomics, no balancing: bounce rays 1.90 ms instead of 1.75), 0.33 with shared pools (bounce rays 1.70).
+// The exact kernels keep private chunks. Small launches draw 64 so that every wave of the grid gets work.
 constexpr uint32_t RAY_CHUNK_SMALL = MIRT_RAY_CHUNK;
 // The fast-tree kernels' loop does one kind of work per iteration, chosen by majority vote of the wave's lanes (the
 // exact kernels keep the while-while form: every lane descends until all stand on a leaf, then all test triangles).
+#ifndef MIRT_GUARD
+#define MIRT_GUARD 0  // debug build: wild indices are reported (printf) and made harmless
+#endif
 #ifndef MIRT_REFILL_MIN
 #define MIRT_REFILL_MIN 24  // idle lanes that trigger a refill (a refill also happens whenever no lane has work left)
 #endif
@@ -194,6 +199,23 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform ray pool
     bool exhausted = false, first_chunk = true;
     const uint32_t wave_id = blockIdx.x * (bs >> 6) + (threadIdx.x >> 6), total_waves = gridDim.x * (bs >> 6);
+    // VOTE loop: the wave's pool lives in LDS (end << 32 | next) so that the other waves of the block can take rays from
+    // it: a wave draws RAY_CHUNK rays from the global queue with ONE atomic (same-address atomics of a whole chip are
+    // served one per ~9 ns, whoever asks: 64 rays per draw would cap a launch at 7 Grays/s), and the block consumes
+    // them in pieces of at most 64, so that the end of a launch is balanced at that granularity, not at RAY_CHUNK.
+    __shared__ unsigned long long s_pool[4];
+    __shared__ int s_dry;  // a wave of the block found the global queue empty
+    const uint32_t wib = threadIdx.x >> 6, nwb = bs >> 6;
+    bool dry = false;      // nothing left for this wave to take, anywhere
+    if (FAST) {
+        if ((threadIdx.x & 63u) == 0) {
+            const uint32_t b0 = wave_id * RAY_CHUNK;
+            s_pool[wib] = b0 < n ? ((unsigned long long)min(b0 + RAY_CHUNK, n) << 32) | b0 : 0ull;
+        }
+        if (threadIdx.x < 4 && threadIdx.x >= nwb) s_pool[threadIdx.x] = 0ull;
+        if (threadIdx.x == 0) s_dry = 0;
+        __syncthreads();
+    }
 
     // per-lane traversal state. `link` is the current child link: >= 0 pair index (inner node),
     // < 0 leaf (~link = begin | count << 24); has = false: nothing left to visit.
@@ -289,27 +311,49 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     for (;;) {
         // ---- refill: lanes without a ray take the next rays of the wave's pool, once enough of them are idle ----
         const unsigned long long need = __ballot(!active);
-        const bool pool_left = !(exhausted && pool_next == pool_end);
-        if (need && pool_left && ((int)__popcll(need) >= MIRT_REFILL_MIN || !__any(active && has))) {
-            if (pool_next == pool_end && !exhausted) {
-                uint32_t base = wave_id * RAY_CHUNK;
-                if (!first_chunk) {
-                    const int leader = __ffsll((long long)need) - 1;
-                    if ((int)lane_id() == leader) base = atomicAdd(queue, RAY_CHUNK);
-                    base = __shfl(base, leader) + total_waves * RAY_CHUNK;
-                }
-                first_chunk = false;
-                if (base >= n) {
-                    exhausted = true;
-                } else {
-                    pool_next = base;
-                    pool_end = min(base + RAY_CHUNK, n);
+        if (need && !dry && ((int)__popcll(need) >= MIRT_REFILL_MIN || !__any(active && has))) {
+            const uint32_t want = (uint32_t)__popcll(need);
+            const int leader = __ffsll((long long)need) - 1;
+            uint32_t nb = 0, take = 0;  // the piece this wave gets: `take` rays from ray nb on
+            // the wave's own pool first, then the other waves' of the block
+            for (uint32_t k = 0; k < nwb && take == 0; k++) {
+                const uint32_t j = (wib + k) & (nwb - 1);  // (1, 2 or 4 waves per block)
+                const unsigned long long v = __hip_atomic_load(&s_pool[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((uint32_t)v < (uint32_t)(v >> 32)) {
+                    unsigned long long got = 0;
+                    if ((int)lane_id() == leader) got = atomicAdd(&s_pool[j], (unsigned long long)want);
+                    const uint32_t b = __shfl((uint32_t)got, leader), e = __shfl((uint32_t)(got >> 32), leader);
+                    if (b < e) {  // (else: emptied by another wave since the look at v)
+                        nb = b;
+                        take = min(e - b, want);
+                    }
                 }
             }
-            const uint32_t take = min(pool_end - pool_next, (uint32_t)__popcll(need));
+            if (take == 0) {  // all empty: draw from the global queue into the own pool, unless that is known to be empty
+                if (!exhausted && __hip_atomic_load(&s_dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) exhausted = true;
+                if (!exhausted) {
+                    uint32_t base = 0;
+                    if ((int)lane_id() == leader) base = atomicAdd(queue, RAY_CHUNK);
+                    base = __shfl(base, leader) + total_waves * RAY_CHUNK;
+                    if (base >= n) {
+                        exhausted = true;
+                        if ((int)lane_id() == leader) __hip_atomic_store(&s_dry, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        const uint32_t e = min(base + RAY_CHUNK, n);
+                        nb = base;
+                        take = min(e - base, want);
+                        if ((int)lane_id() == leader) s_pool[wib] = ((unsigned long long)e << 32) | (base + take);
+                    }
+                }
+                if (take == 0) dry = true;  // (a wave of the block that publishes a pool after this keeps it to itself)
+            }
+            const uint32_t pool_next = nb;
             const uint32_t rank = rank_in(need);
             if (!active && rank < take) {
                 idx = pool_next + rank;
+#if MIRT_GUARD
+                if (idx >= n) { printf("GUARD idx %u n %u nb %u take %u want %u\n", idx, n, nb, take, want); idx = 0; }
+#endif
                 if (ray_list) idx = ray_list[idx];
                 o = mk3(O[idx], O[plane_stride + idx], O[2 * plane_stride + idx]);
                 d = mk3(D[idx], D[plane_stride + idx], D[2 * plane_stride + idx]);
@@ -338,10 +382,9 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 } else if (resolve(root_lo, root_hi, code, lb))
                     enter(__float_as_int(root_lo.w));
             }
-            pool_next += take;
         }
         if (!__any(active)) {
-            if (exhausted && pool_next == pool_end) break;
+            if (dry) break;
             continue;
         }
 
@@ -354,6 +397,10 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
 #pragma unroll
             for (int rep = 0; rep < MIRT_NODE_REPS; rep++)
             if (active && has && link >= 0) {
+#if MIRT_GUARD
+                if (link >= max(sc.n_tris, 1)) { printf("GUARD link %d idx %u sp %u\n", link, idx, sp); link = 0; }
+                if ((sp >> level_shift) > (uint32_t)sc.depth + 1) { printf("GUARD sp %u idx %u\n", sp, idx); sp = 0; }
+#endif
                 const PairRec P = pairs[link];
                 float lbl, lbr;
                 // conservative: only a proven miss is skipped (slab_miss_pair, mirt_dev.h)
@@ -412,7 +459,10 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 const bool on_leaf = active && has && link < 0;
                 if (rep > 0 && !__any(on_leaf)) break;
                 if (COUNT && lane_id() == 0) au.w_leaf++;
-                const int s = (int)(~(uint32_t)link & 0xFFFFFFu);
+                int s = (int)(~(uint32_t)link & 0xFFFFFFu);
+#if MIRT_GUARD
+                if (on_leaf && s >= sc.n_tris) { printf("GUARD leaf slot %d link %d idx %u\n", s, link, idx); s = 0; }
+#endif
                 bool through = false;
                 if (on_leaf) {
                     if (COUNT) au.tri++;
@@ -674,7 +724,10 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
         const f3 d = mk3(D[i], D[plane_stride + i], D[2 * plane_stride + i]);
         const RayPre pre = ray_prepare(sc, o, d);
         const f3 c = mk3(-o.x * pre.inv.x, -o.y * pre.inv.y, -o.z * pre.inv.z);
-        const int slot = id_out[i];
+        int slot = id_out[i];
+#if MIRT_GUARD
+        if (slot >= sc.n_tris || slot < -2) { printf("GUARD verify slot %d ray %u\n", slot, (uint32_t)i); slot = -2; }
+#endif
         if (!pre.fast) {
             redo = true;
         } else if (slot == -2) {  // the fast kernel gave this ray up

@@ -821,3 +821,33 @@ def test_shared_edge_and_duplicate_ties(gpu, ra, orc):
         assert (ic >= 0).mean() > 0.5
     S.close()
     s.close()
+
+
+def test_ragged_batches_touch_nothing_beyond_n(gpu, cornell, cornell_oracle, mesh20k, mesh20k_oracle, ra):
+    """Batch sizes that end inside a 64-ray piece of a wave's pool: every ray below n is answered (against the
+    oracle, starting from sentinel-filled outputs) and nothing at or beyond n is written. The waves of a block share
+    their ray pools (intersect_kernels.h); a pool emptied by another wave between the look at it and the atomic take
+    once came back as a piece of negative length, which was then handed out as 64 rays beyond n."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    pad = 4096
+    for scene, oracle in ((cornell, cornell_oracle), (mesh20k, mesh20k_oracle)):
+        gpu.upload(scene.describe())
+        for n in (1, 63, 65, 4097, 70001, 111130, 1048576 + 37):
+            o = rng.uniform(-0.9, 0.9, (3, n)).astype(np.float32)
+            d = rng.normal(size=(3, n)).astype(np.float32)
+            d /= np.linalg.norm(d, axis=0, keepdims=True)
+            aux = ra.pack_ids(rng.integers(-1, 3, n), np.full(n, -1))
+            to, td, ta = (torch.from_numpy(x).cuda() for x in (o, d, aux))
+            for mode in (ra.MODE_UNCONDITIONAL, ra.MODE_NO_SELF):
+                t = torch.full((n + pad,), -7.0, dtype=torch.float32, device="cuda")
+                i = torch.full((n + pad,), -7, dtype=torch.int32, device="cuda")
+                for rep in range(3):  # (which wave empties which pool is a matter of timing)
+                    gpu.intersect_dev(to.data_ptr(), td.data_ptr(), ta.data_ptr() if mode else None, n, mode,
+                                      t.data_ptr(), i.data_ptr())
+                torch.cuda.synchronize()
+                tg, ig = t.cpu().numpy(), i.cpu().numpy()
+                assert (tg[n:] == -7.0).all() and (ig[n:] == -7).all(), (n, mode, np.nonzero(ig[n:] != -7)[0][:8])
+                tc, ic = oracle.intersect(o, d, aux if mode else None, mode, threads=16)
+                assert np.array_equal(ig[:n], ic) and np.array_equal(tg[:n], tc), (n, mode, int((ig[:n] != ic).sum()))
