@@ -16,7 +16,9 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     rng = np.random.default_rng(seed)
     n_tri = int(10 ** rng.uniform(1.5, 3.7))
     n_obj = 6
-    scene, v = F._soup(ra, rng, n_tri, n_obj)
+    scale = float(10 ** rng.uniform(-2, 2.5)) if seed % 2 else 1.0
+    offset = tuple((rng.uniform(-1, 1, 3) * scale * 8).tolist()) if seed % 4 == 3 else (0.0, 0.0, 0.0)
+    scene, v = F._soup(ra, rng, n_tri, n_obj, scale, offset)
     raw = scene.raw()
     objs = raw["objects"].copy()
     kinds = [ra.OBJ_EMISSIVE, ra.OBJ_DIFFUSE, ra.OBJ_GLOSSY, ra.OBJ_REFRACTIVE, ra.OBJ_PHONG, ra.OBJ_DIFFUSE]
@@ -28,7 +30,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     scene = ra.HostScene.from_arrays(raw["verts"], raw["tris"], raw["tri_obj"], objs, raw["tri_vn"])
     S = orc.OracleScene(scene.raw())
     dev.upload(scene.describe())
-    cam = ra.make_camera(96, 96, 60, position=(0, 0, 3.2))
+    cam = ra.make_camera(96, 96, 60, position=(offset[0], offset[1], offset[2] + 3.2 * scale), focus=offset)
     spp = 32
     for integ in ("pt", "pttest"):
         if integ == "pt":
@@ -40,7 +42,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
             c, nr = S.render_pttest(cam, spp, seed=3, threads=16)[:2]
             c2 = S.render_pttest(cam, spp, seed=103, threads=16)[0]
         same, noise = rmse(g / spp, c / spp), rmse(c / spp, c2 / spp)
-        print("seed %d tris %d %s: same-seed rmse %.3g noise %.3g ratio %.3g | identical pixels %.3f | nan gpu %d cpu %d | rays gpu %d cpu %d | mean %s vs %s" % (
-            seed, n_tri, integ, same, noise, same / max(noise, 1e-30), (g == c).all(-1).mean(), int(np.isnan(g).sum()), int(np.isnan(c).sum()),
+        print("seed %d tris %d scale %.3g %s: same-seed rmse %.3g noise %.3g ratio %.3g | identical pixels %.3f | nan gpu %d cpu %d | rays gpu %d cpu %d | mean %s vs %s" % (
+            seed, n_tri, scale, integ, same, noise, same / max(noise, 1e-30), (g == c).all(-1).mean(), int(np.isnan(g).sum()), int(np.isnan(c).sum()),
             int(st.n_rays), nr, np.nanmean(g / spp, (0, 1)).round(4), np.nanmean(c / spp, (0, 1)).round(4)), flush=True)
     S.close(); scene.close()
