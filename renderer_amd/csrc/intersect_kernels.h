@@ -207,6 +207,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     __shared__ int s_dry;  // a wave of the block found the global queue empty
     const uint32_t wib = threadIdx.x >> 6, nwb = bs >> 6;
     bool dry = false;      // nothing left for this wave to take, anywhere
+    if (FAST && total_waves * RAY_CHUNK >= n) exhausted = true;  // the static first chunks cover the batch: no draw can succeed
     if (FAST) {
         if ((threadIdx.x & 63u) == 0) {
             const uint32_t b0 = wave_id * RAY_CHUNK;
