@@ -343,7 +343,9 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                         const uint32_t e = min(base + RAY_CHUNK, n);
                         nb = base;
                         take = min(e - base, want);
-                        if ((int)lane_id() == leader) s_pool[wib] = ((unsigned long long)e << 32) | (base + take);
+                        if ((int)lane_id() == leader)  // (only the owner writes a pool; the others look and add, atomically)
+                            __hip_atomic_store(&s_pool[wib], ((unsigned long long)e << 32) | (base + take), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
                 if (take == 0) dry = true;  // (a wave of the block that publishes a pool after this keeps it to itself)
