@@ -53,8 +53,8 @@ namespace mirt {
 #ifndef MIRT_LEAF_BATCH
 #define MIRT_LEAF_BATCH 8
 #endif
-// Rays a wave reserves per queue atomic. Same-address atomics of the whole chip are served one per ~9 ns, so the
-// chunk size caps a launch at chunk / 9 ns (64 rays: 7 Grays/s, below what camera rays reach), and a wave that
+// Rays a wave reserves per queue atomic. Same-address atomics of the whole chip are served one per ~11 ns (per 64-byte line), so the
+// chunk size caps a launch at chunk / 11 ns (64 rays: 6 Grays/s, below what camera rays reach), and a wave that
 // waits for its atomic idles. In the fast-tree kernels the chunk is a pool in LDS that the four waves of a block
 // consume together in pieces of <= 64 rays (s_pool below), so the end of a launch is balanced at that granularity
 // whatever the chunk; 4 Mi Cornell camera rays: 0.41 ms with private 256-ray chunks, 0.36 with a static round-robin
@@ -201,7 +201,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     const uint32_t wave_id = blockIdx.x * (bs >> 6) + (threadIdx.x >> 6), total_waves = gridDim.x * (bs >> 6);
     // VOTE loop: the wave's pool lives in LDS (end << 32 | next) so that the other waves of the block can take rays from
     // it: a wave draws RAY_CHUNK rays from the global queue with ONE atomic (same-address atomics of a whole chip are
-    // served one per ~9 ns, whoever asks: 64 rays per draw would cap a launch at 7 Grays/s), and the block consumes
+    // served one per ~11 ns per 64-byte line, whoever asks: 64 rays per draw would cap a launch at 6 Grays/s), and the block consumes
     // them in pieces of at most 64, so that the end of a launch is balanced at that granularity, not at RAY_CHUNK.
     __shared__ unsigned long long s_pool[4];
     __shared__ int s_dry;  // a wave of the block found the global queue empty
