@@ -158,13 +158,23 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
             int* __restrict__ id_out, unsigned long long* __restrict__ counters,
             uint32_t* __restrict__ queue, uint32_t lds_levels, uint2* __restrict__ spill,
             const float* __restrict__ limit = nullptr, unsigned char* __restrict__ vis_out = nullptr,
-            const uint32_t* __restrict__ ray_list = nullptr, uint32_t list_min = 0) {
+            const uint32_t* __restrict__ ray_list = nullptr, uint32_t list_min = 0,
+            const uint32_t* __restrict__ off_ptr = nullptr) {
     extern __shared__ uint32_t lds[];
     constexpr int LEAF_BATCH = LEAF_BATCH_EXACT;
     const PairRec* __restrict__ pairs = FAST ? sc.fpairs : sc.pairs;
     const float4 root_lo = FAST ? sc.froot_lo : sc.root_lo, root_hi = FAST ? sc.froot_hi : sc.root_hi;
     // ray count: given, or (wavefront path tracer) left in device memory by the previous shade pass
     const uint32_t n = n_ptr ? min(*n_ptr, n_direct) : n_direct;
+    // the batch starts at entry *off_ptr of every array (the path tracer's two-ended compaction, pt_kernels.h k_shade)
+    if (off_ptr) {
+        const uint32_t off = *off_ptr;
+        O += off;
+        D += off;
+        if (aux) aux += off;
+        if (t_out) t_out += off;
+        if (id_out) id_out += off;
+    }
     // re-run of a LONG list only (launch_intersect): lists of at most list_min rays belong to k_rerun
     if (ray_list != nullptr && n <= list_min) return;
     const uint32_t bs = blockDim.x;
@@ -717,8 +727,15 @@ __global__ void __launch_bounds__(256)
 k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, uint32_t n_direct,
          const uint32_t* __restrict__ n_ptr, uint32_t plane_stride, const float* __restrict__ t_out,
          int* __restrict__ id_out, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count,
-         unsigned long long* __restrict__ counters) {
+         unsigned long long* __restrict__ counters, const uint32_t* __restrict__ off_ptr = nullptr) {
     const uint32_t n = n_ptr ? min(*n_ptr, n_direct) : n_direct;
+    if (off_ptr) {  // (as in k_intersect; the list holds indices from there on, and k_rerun counts from there too)
+        const uint32_t off = *off_ptr;
+        O += off;
+        D += off;
+        t_out += off;
+        id_out += off;
+    }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool redo = false;
     unsigned long long boxes = 0;
@@ -801,8 +818,17 @@ template <bool SLOT_OUT, int MODE = MIRT_MODE_NO_SELF>
 __global__ void __launch_bounds__(64)
 k_rerun(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, const int* __restrict__ aux,
         uint32_t plane_stride, float* __restrict__ t_out, int* __restrict__ id_out,
-        const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count, uint32_t list_max) {
+        const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count, uint32_t list_max,
+        const uint32_t* __restrict__ off_ptr = nullptr) {
     __shared__ int stack[RERUN_STACK];
+    if (off_ptr) {
+        const uint32_t off = *off_ptr;
+        O += off;
+        D += off;
+        if (aux) aux += off;
+        t_out += off;
+        id_out += off;
+    }
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t count = *list_count;

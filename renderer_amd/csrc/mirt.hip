@@ -77,6 +77,11 @@ struct MirtContext {
     uint32_t* d_ns = nullptr;    // [cnt_cap] shadow rays written by bounce k
     uint32_t* d_wq2 = nullptr;   // [3 * cnt_cap] queue words of the visibility launches (queue head, list length, queue head)
     uint32_t* d_cnt = nullptr;   // [cnt_cap] live paths after k bounces of the running wavefront
+    // two-ended compaction (run_chained, k_shade<.., TWO>): per bounce the two counters, 128 B apart ([64 * k] counts
+    // upwards from the middle of the path buffer, [64 * k + 32] downwards), and where the live range starts
+    uint32_t* d_ab = nullptr;    // [64 * cnt_cap]
+    uint32_t* d_off = nullptr;   // [cnt_cap]
+    const uint32_t* cur_off = nullptr;  // start of the batch the intersect launches being enqueued work on (device word), or null
     uint32_t* d_wq = nullptr;    // [cnt_cap] ray-queue heads, one per intersect launch of the wavefront
     uint32_t* h_cnt = nullptr;   // pinned, [cnt_cap]
     size_t cnt_cap = 0;
@@ -286,6 +291,8 @@ int mirt_destroy(MirtContext* ctx) {
     free_staging(ctx);
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     hipFree(ctx->d_cnt);
+    hipFree(ctx->d_ab);
+    hipFree(ctx->d_off);
     hipFree(ctx->d_wq);
     hipFree(ctx->d_ns);
     hipFree(ctx->d_wq2);
@@ -1142,7 +1149,7 @@ static void launch_pair(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, 
         if (ctx->has_bump) {  // the predicate reads the bumped normal (SceneObject.cpp:250-283)
             hipLaunchKernelGGL((k_intersect<MODE, false, SLOT_OUT, false, false, true>), grid, block, ctx->lds_main, st,
                                ctx->sc, O, D, aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue,
-                               ctx->lds_levels, lb.spill, (const float*)nullptr, (unsigned char*)nullptr, ray_list, list_min);
+                               ctx->lds_levels, lb.spill, (const float*)nullptr, (unsigned char*)nullptr, ray_list, list_min, ctx->cur_off);
             return;
         }
     }
@@ -1150,12 +1157,12 @@ static void launch_pair(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, 
         const dim3 g(std::min<uint32_t>((n + block.x - 1) / block.x, lb.max_blocks_fast));
         hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT, false, true>), g, block, ctx->lds_main_fast, st, ctx->sc, O,
                            D, aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue, ctx->lds_levels_fast,
-                           lb.spill, (const float*)nullptr, (unsigned char*)nullptr, ray_list, list_min);
+                           lb.spill, (const float*)nullptr, (unsigned char*)nullptr, ray_list, list_min, ctx->cur_off);
         return;
     }
     hipLaunchKernelGGL((k_intersect<MODE, COUNT, SLOT_OUT, false, FAST>), grid, block, ctx->lds_main, st, ctx->sc, O, D,
                        aux, n, n_ptr, stride, t_out, id_out, ctx->d_counters, queue, ctx->lds_levels, lb.spill,
-                       (const float*)nullptr, (unsigned char*)nullptr, ray_list, list_min);
+                       (const float*)nullptr, (unsigned char*)nullptr, ray_list, list_min, ctx->cur_off);
 }
 
 template <bool COUNT, bool SLOT_OUT, bool FAST>
@@ -1227,7 +1234,7 @@ static int route_fast(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, in
                                                 qwords, nullptr);
     if (rc != MIRT_OK) return rc;
     hipLaunchKernelGGL((k_verify<SLOT_OUT, COUNT>), dim3((n + 255) / 256), dim3(256), 0, st, ctx->sc, O, D, n, n_ptr, stride,
-                       (const float*)t_out, id_out, lb.list, qwords + 1, ctx->d_counters);
+                       (const float*)t_out, id_out, lb.list, qwords + 1, ctx->d_counters, ctx->cur_off);
     HIPCHK(ctx, hipGetLastError());
     // the listed rays, by the reference arithmetic on the reference tree: one wave per ray (k_rerun); the
     // instrumented call keeps the one-lane-per-ray kernel, whose counters the audit reads
@@ -1237,11 +1244,11 @@ static int route_fast(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, in
         const uint32_t* list = lb.list;
         const uint32_t* count = qwords + 1;
         if (mode == MIRT_MODE_NO_SELF)
-            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_NO_SELF>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count, RERUN_WIDE_MAX);
+            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_NO_SELF>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count, RERUN_WIDE_MAX, ctx->cur_off);
         else if (mode == MIRT_MODE_LAST_TID)
-            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_LAST_TID>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count, RERUN_WIDE_MAX);
+            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_LAST_TID>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count, RERUN_WIDE_MAX, ctx->cur_off);
         else
-            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_UNCONDITIONAL>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count, RERUN_WIDE_MAX);
+            hipLaunchKernelGGL((k_rerun<SLOT_OUT, MIRT_MODE_UNCONDITIONAL>), rg, rb, 0, st, ctx->sc, O, D, aux, stride, t_out, id_out, list, count, RERUN_WIDE_MAX, ctx->cur_off);
         HIPCHK(ctx, hipGetLastError());
         // a list longer than that (whole batches outside the classifier's model: axis-parallel rays) is re-run with one
         // lane per ray by the persistent exact kernel; each of the two launches returns at once when the list is the other's
@@ -1603,6 +1610,7 @@ static int make_camera(MirtContext* ctx, const MirtCamera* c, DevCamera* out) {
 }
 
 static int alloc_pathbuf(MirtContext* ctx, PathBuf& p, size_t cap) {
+    cap += 256;  // two-ended compaction fills [mid - B, mid + A) with mid a multiple of the block size: up to 255 entries beyond the bound
     HIPCHK(ctx, hipMalloc(&p.o, 3 * cap * sizeof(float)));
     HIPCHK(ctx, hipMalloc(&p.d, 3 * cap * sizeof(float)));
     HIPCHK(ctx, hipMalloc(&p.thr, 3 * cap * sizeof(float)));
@@ -1682,13 +1690,17 @@ static int ensure_counts(MirtContext* ctx, hipStream_t st, size_t words) {
     if (words <= ctx->cnt_cap) return MIRT_OK;
     HIPCHK(ctx, hipStreamSynchronize(st));
     hipFree(ctx->d_cnt);
+    hipFree(ctx->d_ab);
+    hipFree(ctx->d_off);
     hipFree(ctx->d_wq);
     hipFree(ctx->d_ns);
     hipFree(ctx->d_wq2);
     hipHostFree(ctx->h_cnt);
-    ctx->d_cnt = ctx->d_wq = ctx->d_ns = ctx->d_wq2 = ctx->h_cnt = nullptr;
+    ctx->d_cnt = ctx->d_ab = ctx->d_off = ctx->d_wq = ctx->d_ns = ctx->d_wq2 = ctx->h_cnt = nullptr;
     ctx->cnt_cap = 0;
     HIPCHK(ctx, hipMalloc(&ctx->d_cnt, words * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->d_ab, 64 * words * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->d_off, words * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->d_wq, 3 * words * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->d_ns, words * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->d_wq2, 3 * words * sizeof(uint32_t)));
@@ -1859,17 +1871,21 @@ static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderP
         if (w >= (uint32_t)gens && (rc = accumulate(w - gens)) != MIRT_OK) return rc;  // its buffer is reused now
         HIPCHK(ctx, hipMemsetAsync(ctx->d_L + (size_t)g * 3 * cap, 0, 3 * cap * sizeof(float), st));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt, 0, words * sizeof(uint32_t), st));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_ab, 0, 64 * words * sizeof(uint32_t), st));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_wq, 0, 3 * words * sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_generate, dim3((P + B - 1) / B), dim3(B), 0, st, cam, P, prm->spp_begin + w * S, prm->seed, cur->o,
                            cur->d, cur->stride, *cur, 1, g << PID_GEN_SHIFT);
         HIPCHK(ctx, hipGetLastError());
-        auto timed_intersect = [&](int mode, PathBuf* pb, uint32_t n, const uint32_t* n_ptr, uint32_t* queue) -> int {
+        auto timed_intersect = [&](int mode, PathBuf* pb, uint32_t n, const uint32_t* n_ptr, uint32_t* queue,
+                                   const uint32_t* off = nullptr) -> int {
             hipEvent_t e0 = get_event(ctx, *ev_used), e1 = get_event(ctx, *ev_used + 1);
             if (!e0 || !e1) return fail(ctx, MIRT_E_HIP, "hipEventCreate failed");
             *ev_used += 2;
             HIPCHK(ctx, hipEventRecord(e0, st));
+            ctx->cur_off = off;  // (where the batch starts in pb's arrays: two-ended compaction)
             const int r = launch_intersect<false, true>(ctx, st, mode, pb->o, pb->d, pb->ids, n, pb->stride, pb->t, pb->slot,
                                                         n_ptr, queue);
+            ctx->cur_off = nullptr;
             if (r != MIRT_OK) return r;
             HIPCHK(ctx, hipEventRecord(e1, st));
             return MIRT_OK;
@@ -1886,13 +1902,20 @@ static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderP
         carried = 0;
         for (uint32_t it = 0; it <= prm->max_depth; it++) {
             const uint32_t* n_in = (it || counted_start) ? ctx->d_cnt + it : nullptr;
+            const uint32_t* off_in = it ? ctx->d_off + it : nullptr;  // (camera hits and carried paths lie at [0, n))
             uint32_t* n_out = ctx->d_cnt + it + 1;
+            uint32_t* off_out = ctx->d_off + it + 1;
+            uint32_t* ab = ctx->d_ab + 64 * (size_t)(it + 1);
+            // two-ended compaction (pt_kernels.h, k_shade<.., TWO>): survivors land in [mid - ab[32], mid + ab[0])
+            const uint32_t sgrid = (bound + SHADE_BLOCK - 1) / SHADE_BLOCK, mid = (sgrid >> 1) * (uint32_t)SHADE_BLOCK;
             if (ctx->has_media)
-                hipLaunchKernelGGL(k_shade<true>, dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
-                                   n_out, ctx->d_L, (uint32_t)cap, prm->max_depth);
+                hipLaunchKernelGGL((k_shade<true, false, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
+                                   ab, ctx->d_L, (uint32_t)cap, prm->max_depth, ShadowBuf{}, (uint32_t*)nullptr, off_in);
             else
-                hipLaunchKernelGGL(k_shade<false>, dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
-                                   n_out, ctx->d_L, (uint32_t)cap, prm->max_depth);
+                hipLaunchKernelGGL((k_shade<false, false, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
+                                   ab, ctx->d_L, (uint32_t)cap, prm->max_depth, ShadowBuf{}, (uint32_t*)nullptr, off_in);
+            HIPCHK(ctx, hipGetLastError());
+            hipLaunchKernelGGL(k_live, dim3(1), dim3(1), 0, st, (const uint32_t*)ab, mid, n_out, off_out);
             HIPCHK(ctx, hipGetLastError());
             depths_run = it + 1;
             if (it == prm->max_depth) break;  // (camera paths end here; carried ones ended earlier, by their own depth)
@@ -1906,11 +1929,11 @@ static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderP
                 bound = n;
                 if (n == 0) break;
             }
-            rc = timed_intersect(MIRT_MODE_NO_SELF, cur, bound, n_out, ctx->d_wq + 3 * (it + 1));  // MCRenderer.cpp:193-197
+            rc = timed_intersect(MIRT_MODE_NO_SELF, cur, bound, n_out, ctx->d_wq + 3 * (it + 1), off_out);  // MCRenderer.cpp:193-197
             if (rc != MIRT_OK) return rc;
             if (at_cut && bound <= carry_limit) {
                 hipLaunchKernelGGL(k_carry, dim3((bound + B - 1) / B), dim3(B), 0, st, *cur, (const uint32_t*)n_out, bound, ctx->carry, 0u,
-                                   ctx->d_carry_cnt, 0u);
+                                   ctx->d_carry_cnt, 0u, (const uint32_t*)off_out);
                 HIPCHK(ctx, hipGetLastError());
                 carried = bound;
                 break;

@@ -38,6 +38,11 @@ struct PathBuf {
                      //             that vertex was DEFINITE / there is none (lastSpecular, PathTracerTest.cpp:29-30)
     uint32_t stride;
 };
+// the same buffers seen from entry `off` on (two-ended compaction: the live paths of a bounce are [off, off + n))
+__device__ __forceinline__ void shift_paths(PathBuf& b, uint32_t off) {
+    b.o += off; b.d += off; b.thr += off; b.t += off; b.slot += off; b.key += off; b.ctr += off; b.ids += off;
+    b.pid += off; b.lpw += off;
+}
 
 // Shadow rays of one bounce of PathTracerTest (colorByConnectingLights, PathTracerTest.cpp:85-135):
 // what the visibility launch reads (o, d, ids, lim) and what k_connect adds to L when unoccluded.
@@ -588,11 +593,18 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
 #define MIRT_SHADE_BLOCK 256
 #endif
 constexpr int SHADE_BLOCK = MIRT_SHADE_BLOCK, SHADE_WAVES = MIRT_SHADE_BLOCK / 64;
-template <bool VOL, bool NEE = false>
+// TWO (run_chained): two-ended compaction. Every block ends on one atomic for its room in the output, and atomics on
+// one 64-byte line are served one per 11.4 ns whoever asks (scripts/experiments/atomic_rate.hip): 143 000 blocks of a
+// 32 Mi wavefront's first bounce = 1.6 ms, which is what that launch took (1.13 ms with half of the atomics left out).
+// So blocks with an even index count upwards from the middle of the buffer (n_out[0]) and blocks with an odd index
+// downwards (n_out[32], 128 B away): the survivors are the dense range [mid - n_out[32], mid + n_out[0]), whose start
+// and length k_live hands to the consumers (off_in here, off_ptr of the traversal kernels).
+template <bool VOL, bool NEE = false, bool TWO = false>
 __global__ void __launch_bounds__(MIRT_SHADE_BLOCK)
 k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_in, uint32_t n_max,
         PathBuf out, uint32_t* __restrict__ n_out, float* __restrict__ L, uint32_t L_stride,
-        uint32_t max_depth, ShadowBuf sh = ShadowBuf{}, uint32_t* __restrict__ n_sh = nullptr) {
+        uint32_t max_depth, ShadowBuf sh = ShadowBuf{}, uint32_t* __restrict__ n_sh = nullptr,
+        const uint32_t* __restrict__ off_in = nullptr) {
     __shared__ uint32_t s_wcnt[SHADE_WAVES];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_wcnt2[SHADE_WAVES];
@@ -600,6 +612,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
     __shared__ uint32_t s_off[SHADE_WAVES][8];  // start of every (wave, class) run inside the block, class-major
     const uint32_t n = n_in ? min(*n_in, n_max) : n_max;
     if (blockIdx.x * blockDim.x >= n) return;  // the grid is sized for n_max; whole block, before any barrier
+    if (off_in) shift_paths(in, *off_in);
 #if MIRT_SHADE_BIN
     // ---- which path this lane shades: the block's 256 paths, regrouped by the material that will run ------------
     // Neighbouring paths hit different objects, and every material is its own long branch (Lambert / Phong lobe /
@@ -872,7 +885,14 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
     if (threadIdx.x == 0) {
         uint32_t tot = 0, tot2 = 0;
         for (int k = 0; k < SHADE_WAVES; k++) tot += s_wcnt[k];
-        s_base = tot ? atomicAdd(n_out, tot) : 0u;
+        if (TWO) {
+            const uint32_t mid = (gridDim.x >> 1) * (uint32_t)SHADE_BLOCK;  // (k_live is given the same value)
+            if (!tot) s_base = 0u;
+            else if (blockIdx.x & 1u) s_base = mid - (atomicAdd(n_out + 32, tot) + tot);
+            else s_base = mid + atomicAdd(n_out, tot);
+        } else {
+            s_base = tot ? atomicAdd(n_out, tot) : 0u;
+        }
         if (NEE) {
             for (int k = 0; k < SHADE_WAVES; k++) tot2 += s_wcnt2[k];
             s_base2 = tot2 ? atomicAdd(n_sh, tot2) : 0u;
@@ -958,8 +978,9 @@ k_accumulate(const float* __restrict__ L, uint32_t L_stride, uint32_t wh, uint32
 // buffer, and from there behind the next wavefront's camera hits.
 __global__ void __launch_bounds__(256)
 k_carry(PathBuf src, const uint32_t* __restrict__ n_src, uint32_t n_max, PathBuf dst, uint32_t dst_off,
-        uint32_t* __restrict__ cnt_out, uint32_t cnt_base) {
+        uint32_t* __restrict__ cnt_out, uint32_t cnt_base, const uint32_t* __restrict__ off_src = nullptr) {
     const uint32_t n = min(*n_src, n_max);
+    if (off_src) shift_paths(src, *off_src);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *cnt_out = cnt_base + n;
     if (i >= n) return;
@@ -973,6 +994,13 @@ k_carry(PathBuf src, const uint32_t* __restrict__ n_src, uint32_t n_max, PathBuf
     dst.ctr[j] = src.ctr[i];
     dst.ids[j] = src.ids[i];
     dst.pid[j] = src.pid[i];
+}
+
+// two-ended compaction (k_shade<.., TWO>): length and start of the range the two counters describe
+__global__ void k_live(const uint32_t* __restrict__ ab, uint32_t mid, uint32_t* __restrict__ n_out,
+                       uint32_t* __restrict__ off_out) {
+    *n_out = ab[0] + ab[32];
+    *off_out = mid - ab[32];
 }
 
 // a[i] += b[i]: the reduce step of mirt_render_pt_multi (context k's radiance sums into context 0's)
