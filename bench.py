@@ -338,7 +338,9 @@ def main():
         for w in ("mesh1m", "fog"):
             torch.cuda.empty_cache()
             sec, (scene, cam, scene_name, dev) = closest_hit_section(w, args, rank, world, local, barrier, tstream, want_cpu)
-            if w == "fog":  # configs[4]: the medium's path tracing (distance + phase sampling inside the wavefront loop)
+            # fog: configs[4], the medium's path tracing (distance + phase sampling inside the wavefront loop);
+            # mesh1m: the metric names path-traced samples/s on the 1 M-triangle mesh too
+            if w in ("fog", "mesh1m"):
                 fpt = path_tracing_section(dev, cam, scene_name, max(args.pt_spp // 8, world), rank, world, barrier)
                 if rank == 0:
                     sec["path_tracing"] = fpt
