@@ -213,6 +213,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     // it: a wave draws RAY_CHUNK rays from the global queue with ONE atomic (same-address atomics of a whole chip are
     // served one per ~11 ns per 64-byte line, whoever asks: 64 rays per draw would cap a launch at 6 Grays/s), and the block consumes
     // them in pieces of at most 64, so that the end of a launch is balanced at that granularity, not at RAY_CHUNK.
+    static_assert(MIRT_BLOCK >= 64 && MIRT_BLOCK <= 256 && (MIRT_BLOCK & (MIRT_BLOCK - 1)) == 0,
+                  "the shared ray pools (s_pool, the steal loop's mask) are written for 1, 2 or 4 waves per block");
     __shared__ unsigned long long s_pool[4];
     __shared__ int s_dry;  // a wave of the block found the global queue empty
     const uint32_t wib = threadIdx.x >> 6, nwb = bs >> 6;
@@ -252,6 +254,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     pre.inv = mk3(0, 0, 0);
     pre.a_ray = 0.f;
     pre.fast = false;
+    pre.near = false;
     RayPre2 pre2 = ray_pairs(o, d, pre);
 
     // does the box pass the reference test? Decided by the slab classifier when it can prove the
@@ -391,7 +394,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 const int code = slab_classify(root_lo, root_hi, box_is_flat(root_lo, root_hi), o, pre, lb);
                 if (FAST) {
                     if (COUNT) au.box++;
-                    if (pre.fast && code != BOX_MISS) enter(__float_as_int(root_lo.w));
+                    if (pre.fast && pre.near && code != BOX_MISS) enter(__float_as_int(root_lo.w));
                 } else if (resolve(root_lo, root_hi, code, lb))
                     enter(__float_as_int(root_lo.w));
             }
@@ -748,7 +751,7 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
 #if MIRT_GUARD
         if (slot >= sc.n_tris || slot < -2) { printf("GUARD verify slot %d ray %u\n", slot, (uint32_t)i); slot = -2; }
 #endif
-        if (!pre.fast) {
+        if (!pre.fast || !pre.near) {  // outside the classifier's model, or too far out for the fast tree's padded leaves
             redo = true;
         } else if (slot == -2) {  // the fast kernel gave this ray up
             redo = true;

@@ -407,8 +407,8 @@ struct FastTree {
 // not nearly parallel to that edge); where two edges meet at an angle theta the accepted region reaches beyond the
 // corner by that over sin(theta). A well-shaped triangle gets ~1e-5 of the scene's size, a needle (found by
 // tests/test_gpu_fuzz.py: a sliver 1e-4 wide accepted 2e-4 beyond its tip) up to the whole reference leaf box, to
-// which build_fast_tree clips. bound: largest coordinate magnitude of the scene; rays are assumed to start within
-// four times that.
+// which build_fast_tree clips. bound: largest coordinate magnitude of the scene; the pad is sized for rays that
+// start within four times that, and only those take the fast route (DevScene::far_o, RayPre::near in mirt_dev.h).
 static void tri_fast_box(const float* p, float bound, float* mn, float* mx) {
     double sin_min = 1.0;
     for (int c = 0; c < 3; c++) {
@@ -1065,6 +1065,7 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     HIPCHK(ctx, hipMemcpy(ctx->d_objs, objs.data(), sizeof(DevObject) * (size_t)s->n_objects, hipMemcpyHostToDevice));
     for (int c = 0; c < 3; c++) ctx->sc.bound[c] = bound[c];
     ctx->sc.fast_ok = fast_ok;
+    ctx->sc.far_o = 4.f * std::max(bound[0], std::max(bound[1], bound[2]));  // (tri_fast_box's assumption, enforced: RayPre::near)
     ctx->sc.pairs = ctx->d_pairs;
     ctx->sc.root_lo = root_lo;
     ctx->sc.root_hi = root_hi;

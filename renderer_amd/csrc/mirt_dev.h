@@ -141,6 +141,8 @@ struct DevScene {
     const struct DevBump* bumps;  // bump textures of the objects that have one (VnRec.n2.w bits 8..)
     int has_bump;
     int fast_ok;          // node bounds finite, < 2^60, extent per axis 0 or >= 2^-36: the slab classifier may be used
+    float far_o;          // 4 x the largest |coordinate| of the root box: rays that start farther out than this are not
+                          // walked through the fast tree (RayPre::near; tri_fast_box in mirt.hip sizes its pad for this)
 };
 
 struct f3 {
@@ -242,6 +244,11 @@ struct RayPre {
     f3 inv;       // RN(1/d) per axis
     float a_ray;  // absolute part of the margin: 16 eps * max_a (|o_a| + bound_a) * |inv_a|
     bool fast;    // the classifier's error model holds for this ray
+    bool near;    // the origin lies within DevScene::far_o of the coordinate origin. The fast tree's single-triangle
+                  // boxes are padded by the reach of the reference's edge-sign rounding (mirt.hip tri_fast_box), which
+                  // grows with |v - o|: the pad is sized for origins within 4 x the scene's bound, so only such rays may
+                  // take the fast route (k_intersect<FAST> skips the others, k_verify lists them for the exact re-run).
+                  // The exact kernels do not look at it: the classifier's margin a_ray scales with |o| by itself.
 };
 
 __device__ __forceinline__ bool in_range(float v, float lo, float hi) {
@@ -256,6 +263,7 @@ __device__ __forceinline__ RayPre ray_prepare(const DevScene& sc, f3 o, f3 d) {
     p.fast = sc.fast_ok != 0 && in_range(d.x, lo_d, hi_d) && in_range(d.y, lo_d, hi_d) &&
              in_range(d.z, lo_d, hi_d) && (o.x == 0.f || in_range(o.x, lo_o, hi_o)) &&
              (o.y == 0.f || in_range(o.y, lo_o, hi_o)) && (o.z == 0.f || in_range(o.z, lo_o, hi_o));
+    p.near = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= sc.far_o;  // (false for NaN)
     p.inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
     float ax = (fabsf(o.x) + sc.bound[0]) * fabsf(p.inv.x);
     float ay = (fabsf(o.y) + sc.bound[1]) * fabsf(p.inv.y);

@@ -62,7 +62,15 @@ struct DevCamera {
     int width, height;
     float sight;               // float(sightDist)
     double half_w, half_h;     // width/2.0, height/2.0 (double, Camera.cpp:21)
+    // the pixel window this render covers (MirtTile, include/mirt.h; the whole image: 0, 0, width, height). Paths,
+    // radiance slots and the caller's accumulator are indexed by the LOCAL pixel ly * tw + lx; the camera ray, the RNG
+    // stream and the vignetting term use the pixel of the full image, so a tile's values are the full frame's.
+    int tx0, ty0, tw, th;
 };
+// local pixel of the window -> pixel of the full image
+__device__ __forceinline__ uint32_t tile_pixel(const DevCamera& c, uint32_t lp) {
+    return ((uint32_t)c.ty0 + lp / (uint32_t)c.tw) * (uint32_t)c.width + (uint32_t)c.tx0 + lp % (uint32_t)c.tw;
+}
 
 // ---- counter RNG (DESIGN.md "RNG"): replaces the global MT19937 of RandGenerator.cpp:9 -------------
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
@@ -108,14 +116,14 @@ k_generate(DevCamera cam, uint32_t n, uint32_t spp_begin, uint32_t seed, float* 
            float* __restrict__ D, uint32_t stride, PathBuf pb, int fill_state, uint32_t pid_gen = 0) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t wh = (uint32_t)cam.width * (uint32_t)cam.height;
-    uint32_t pixel = i % wh, sample = spp_begin + i / wh;
+    uint32_t wh = (uint32_t)cam.tw * (uint32_t)cam.th;
+    uint32_t pixel = i % wh, sample = spp_begin + i / wh;  // (pixel of the window; of the full image from tile_pixel on)
     // The wavefront path tracer's own camera pass walks the image in 16 x 16 tiles (256 consecutive rays = one
     // tile = one ray chunk of a traversal wave, intersect_kernels.h): neighbours in the batch are neighbours on
     // the screen in both directions. Sample streams and radiance slots are keyed by (pixel, sample), so the
     // image does not depend on this order. The public ray generator (fill_state 0) keeps the documented one.
-    if (fill_state && (cam.width & 15) == 0 && (cam.height & 15) == 0) {
-        const uint32_t tile = pixel >> 8, within = pixel & 255u, tiles_x = (uint32_t)cam.width >> 4;
+    if (fill_state && (cam.tw & 15) == 0 && (cam.th & 15) == 0) {
+        const uint32_t tile = pixel >> 8, within = pixel & 255u, tiles_x = (uint32_t)cam.tw >> 4;
 #if MIRT_TILE_MORTON
         // inside the tile along a Z curve: any 64 consecutive rays (one refill of a wave) cover an 8 x 8 block
         auto even_bits = [](uint32_t v) {
@@ -128,8 +136,10 @@ k_generate(DevCamera cam, uint32_t n, uint32_t spp_begin, uint32_t seed, float* 
 #else
         const uint32_t wx = within & 15u, wy = within >> 4;
 #endif
-        pixel = ((tile / tiles_x) * 16u + wy) * (uint32_t)cam.width + (tile % tiles_x) * 16u + wx;
+        pixel = ((tile / tiles_x) * 16u + wy) * (uint32_t)cam.tw + (tile % tiles_x) * 16u + wx;
     }
+    const uint32_t local_pixel = pixel;
+    pixel = tile_pixel(cam, local_pixel);
     uint32_t key = stream_key(seed, pixel, sample), ctr = 0;
     float u = rng_float(key, ctr);
     float v = rng_float(key, ctr);
@@ -149,7 +159,7 @@ k_generate(DevCamera cam, uint32_t n, uint32_t spp_begin, uint32_t seed, float* 
         pb.key[i] = key;
         pb.ctr[i] = ctr;
         pb.ids[i] = MIRT_PACK_IDS(-1, -1);
-        pb.pid[i] = ((i / wh) * wh + pixel) | pid_gen;  // sample_local * W*H + pixel, whatever the order of the batch
+        pb.pid[i] = ((i / wh) * wh + local_pixel) | pid_gen;  // sample_local * (window pixels) + local pixel, whatever the order of the batch
     }
 }
 
@@ -840,7 +850,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
             nd = sr.nd;
             if (sr.emitted) {
                 const uint32_t px = pid & PID_MASK;
-                float vd = vignette_div(cam, px % ((uint32_t)cam.width * (uint32_t)cam.height));
+                float vd = vignette_div(cam, tile_pixel(cam, px % ((uint32_t)cam.tw * (uint32_t)cam.th)));
                 f3 rad = div3(thr, vd);
                 Lg[px] = rad.x;
                 Lg[L_stride + px] = rad.y;
@@ -955,22 +965,24 @@ k_connect(ShadowBuf sh, const uint32_t* __restrict__ n_ptr, uint32_t n_max, floa
     L[2 * L_stride + pid] += sh.c[2 * sh.stride + j];
 }
 
-// rgb_sum[p] += sum over the launch's samples of L, in sample order (deterministic).
+// rgb_sum[p] = (..((rgb_sum[p] + L_0) + L_1) + ..): the launch's samples are added ONE BY ONE, in sample order, to what
+// the accumulator already holds, so the image is the same fp32 sum however the samples are cut into wavefronts
+// (spp_per_launch, the automatic width, a tile's smaller wavefronts): deterministic, and bit-equal across those choices.
 __global__ void __launch_bounds__(256)
 k_accumulate(const float* __restrict__ L, uint32_t L_stride, uint32_t wh, uint32_t n_samples,
              float* __restrict__ rgb_sum) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= wh) return;
-    float r = 0.f, g = 0.f, b = 0.f;
+    float r = rgb_sum[3 * p], g = rgb_sum[3 * p + 1], b = rgb_sum[3 * p + 2];
     for (uint32_t s = 0; s < n_samples; s++) {
         uint32_t k = s * wh + p;
         r += L[k];
         g += L[L_stride + k];
         b += L[2 * L_stride + k];
     }
-    rgb_sum[3 * p] += r;
-    rgb_sum[3 * p + 1] += g;
-    rgb_sum[3 * p + 2] += b;
+    rgb_sum[3 * p] = r;
+    rgb_sum[3 * p + 1] = g;
+    rgb_sum[3 * p + 2] = b;
 }
 
 // Wavefront chaining (mirt.hip run_chained): moves the n = min(*n_src, n_max) intersected paths src[0, n) to

@@ -195,3 +195,41 @@ def test_soup_bounce_and_edge_parallel_rays(gpu, ra, orc, seed, n_tri, scale, of
         assert nd <= 5e-4 * n, (mode, nd)
     S.close()
     scene.close()
+
+
+@pytest.mark.parametrize("seed,n_tri,far", [(31, 2500, 6.0), (32, 2500, 40.0), (33, 800, 1000.0)])
+def test_far_origin_rays_against_oracle(gpu, ra, orc, seed, n_tri, far):
+    """Rays that start `far` scene sizes outside the scene, aimed at corners, edge midpoints and interiors of the soup's
+    triangles (slivers included). The reach of the reference's edge-sign rounding beyond a triangle's outline grows
+    with |v - o|, and the fast tree's single-triangle boxes are padded for origins within 4 x the scene's bound only
+    (mirt.hip tri_fast_box): such rays must not take the fast route (RayPre::near) and the answers must stay the
+    oracle's, bit for bit, in all three modes."""
+    rng = np.random.default_rng(4000 + seed)
+    n_obj = 5
+    scene, v = _soup(ra, rng, n_tri, n_obj)
+    S = orc.OracleScene(scene.raw())
+    gpu.upload(scene.describe())
+    n = 60000
+    T = len(v)
+    k = rng.integers(0, T, n)
+    w = rng.dirichlet((1, 1, 1), n)
+    pick = rng.integers(0, 4, n)
+    w[pick == 0] = (1, 0, 0)
+    w[pick == 1] = (0.5, 0.5, 0)
+    target = (v[k].astype(np.float64) * w[:, :, None]).sum(1)
+    target += (rng.random((n, 1)) < 0.3) * 1e-5 * rng.normal(size=(n, 3))  # some just beside the corner / edge
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    oo = u * far * rng.uniform(0.8, 1.2, (n, 1))
+    dd = target - oo
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    o, d = np.ascontiguousarray(oo.T, np.float32), np.ascontiguousarray(dd.T, np.float32)
+    aux = ra.pack_ids(rng.integers(-1, n_obj, n), np.full(n, -1))
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_LAST_TID, k.astype(np.int32)), (ra.MODE_NO_SELF, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = S.intersect(o, d, a, mode, threads=16)
+        nd = int(((ig != ic) | ~((tg == tc) | (np.isnan(tg) & np.isnan(tc)))).sum())
+        print("far origins x%g seed %d mode %d: hit rate %.2f, %d of %d rays differ" % (far, seed, mode, (ic >= 0).mean(), nd, n))
+        assert nd == 0, (mode, nd)
+    S.close()
+    scene.close()
