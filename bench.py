@@ -37,12 +37,15 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import renderer_amd as ra  # noqa: E402
-from renderer_amd.multi_gpu import reduce_radiance_sums  # noqa: E402
+from renderer_amd.multi_gpu import gather_tiles, reduce_radiance_sums  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# VALU lane-issue roof: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one wave64 VALU instruction holds its SIMD for 4 cycles)
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 PRIMARY_SPP = 4
 N_SECONDARY = 12 << 20
-PROFILE_ROUND = "r2"
+PROFILE_ROUND = "r3"
+STALE_TOLERANCE = 0.15  # committed profile vs this run's HIP-event time of the same kernels
 
 
 def algorithmic_bytes(n_rays, n_box, n_tri):
@@ -64,9 +67,10 @@ def build_scene(workload):
 
 
 def committed_profile(workload):
-    """HBM-side bytes and issue-slot figures of one closest-hit call in the predicate mode on this workload's batch,
-    from the committed rocprofv3 passes of `bench.py --workload X` (PMC counters cannot be read from inside this
-    process): profiles/<round>_<workload>_traffic.json, written by scripts/summarize_profile.py."""
+    """HBM-side bytes, issue-slot figures and average kernel times of one closest-hit call in the predicate mode on this
+    workload's batch, from the committed rocprofv3 passes of `bench.py --workload X` (PMC counters cannot be read from
+    inside this process): profiles/<round>_<workload>_traffic.json, written by scripts/summarize_profile.py. The caller
+    checks the profile's kernel times against this run's before using it (STALE_TOLERANCE)."""
     path = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (PROFILE_ROUND, workload))
     if not os.path.exists(path):
         return None, None
@@ -176,67 +180,96 @@ def closest_hit_section(workload, args, rank, world, local, barrier, tstream, wa
         },
     }
     # ---- roofline of the dominant launch sequence: one closest-hit call in the predicate mode ---------------
+    # The contract's figure is the ALGORITHMIC byte rate. On these scenes the tree is served from
+    # L1 / L2 / Infinity Cache, so that rate exceeds the HBM peak and is no roofline position:
+    # it is kept as algorithmic_rate_GBs. `bound` / `frac` state the resource that binds, VALU issue under
+    # divergence: frac = (share of the VALU issue slots used) x (active lanes / 64) of the dominant kernel, from the
+    # committed PMC passes of this very command (PMC counters cannot be read from inside this process), guarded
+    # against staleness by this run's own HIP-event time; hbm_measured_frac is the counters' HBM-side byte rate.
     sec_bytes = algorithmic_bytes(n_sec, sb, str_)
-    ach = sec_bytes / (sec_ms * 1e-3) / 1e9 if sec_ms > 0 else 0.0
+    alg_rate = sec_bytes / (sec_ms * 1e-3) / 1e9 if sec_ms > 0 else 0.0
     prof, prof_path = committed_profile(workload)
-    traffic_bytes, traffic_src, issue = None, None, None
-    if prof and n_sec == N_SECONDARY:
+    rl = {"bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlane-op/s",
+          "frac": None, "traffic": None, "traffic_source": None}
+    names = []
+    if prof:
         ks = prof["kernels"]
         # one closest-hit call in the predicate mode = fast-tree launch + k_verify + exact re-run
         names = [n for n in sorted(ks) if n.startswith("k_intersect<2, false, false, false, true")
                  or n.startswith("k_verify<false, false") or n.startswith("k_rerun<false, 2")]
-        if names:
-            traffic_bytes = int(sum(ks[n]["read_bytes"] + ks[n]["write_bytes"] for n in names))
-            traffic_src = ("%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean per dispatch, summed over the %d "
-                           "kernels of one call)" % (prof_path, len(names)))
-            main = ks[names[0]]
-            if main.get("valu_issue_frac") is not None:
-                issue = {"kernel": names[0], "valu_issue_frac": main["valu_issue_frac"],
-                         "lanes_active_of_64": main["lanes_active_of_64"], "l2_hit_rate": main.get("l2_hit_rate"),
-                         "definition": "valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE per "
-                                       "XCD); lanes_active_of_64 = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU (as "
-                                       "scripts/summarize_profile.py prints them)",
-                         "source": prof_path}
-    sec["roofline"] = {
-        "bound": "hbm",
+    if names and n_sec == N_SECONDARY and sec_ms > 0 and all(ks[n].get("avg_us") for n in names):
+        prof_ms = sum(ks[n]["avg_us"] for n in names) / 1e3
+        main = ks[names[0]]
+        rl["profile"] = {"source": prof_path, "kernels": names, "kernel_ms_in_profile": round(prof_ms, 4),
+                         "dominant_kernel_ms_in_profile": round(main["avg_us"] / 1e3, 4)}
+        if abs(prof_ms - sec_ms) <= STALE_TOLERANCE * prof_ms and main.get("valu_issue_frac") is not None:
+            frac = main["valu_issue_frac"] * main["lanes_active_of_64"] / 64.0
+            rd_lo = sum(ks[n]["read_bytes"] for n in names)
+            rd_hi = sum(ks[n]["read_bytes_x2"] for n in names)
+            wr = sum(ks[n]["write_bytes"] for n in names)
+            rl.update({
+                "achieved": round(frac * VALU_PEAK_TLANEOPS, 3), "frac": round(frac, 4),
+                "traffic": int(rd_hi + wr),
+                "traffic_source": "%s: rocprofv3 --pmc FETCH_SIZE (x2: upper bound, every request counted as 128 B) + "
+                                  "WRITE_SIZE, mean per dispatch, summed over the %d kernels of one call" % (prof_path, len(names)),
+                "traffic_read_bytes_range": [int(rd_lo), int(rd_hi)],
+                "hbm_measured_frac": round((rd_hi + wr) / (sec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "hbm_measured_frac_range": [round((rd_lo + wr) / (sec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                            round((rd_hi + wr) / (sec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)],
+                "issue": {"kernel": names[0], "valu_issue_frac": main["valu_issue_frac"],
+                          "lanes_active_of_64": main["lanes_active_of_64"], "l2_hit_rate": main.get("l2_hit_rate"),
+                          "definition": "valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD); "
+                                        "lanes_active_of_64 = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU; frac = their product / 64 "
+                                        "(scripts/summarize_profile.py)"}})
+        else:
+            rl["traffic_source"] = "stale"  # the committed profile is of other kernels / another machine state
+            rl["stale_reason"] = ("kernel time of the committed profile (%.3f ms) and of this run (%.3f ms) differ by more "
+                                  "than %d %%" % (prof_ms, sec_ms, int(STALE_TOLERANCE * 100)))
+    rl.update({
         "kernel": "one mirt_intersect_dev call in MODE_NO_SELF on the secondary batch (%d rays): k_intersect<NO_SELF, FAST> "
-                  "over the fast tree (the dominant launch, ~90 %% of kernel_ms) + k_verify + k_rerun, the exact re-run "
-                  "of the rays it rejected, one wave per ray" % n_sec,
-        "achieved": round(ach, 1),
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": round(ach / HBM_PEAK_GBS, 4),
-        "traffic": traffic_bytes,
-        "traffic_source": traffic_src,
+                  "over the fast tree (the dominant launch) + k_verify + k_rerun, the exact re-run of the rays it rejected, "
+                  "one wave per ray" % n_sec,
         "kernel_ms": round(sec_ms, 4),
         "algorithmic_bytes_per_launch": sec_bytes,
+        "algorithmic_rate_GBs": round(alg_rate, 1),
+        "algorithmic_rate_over_hbm_peak": round(alg_rate / HBM_PEAK_GBS, 4),
         "bytes_per_ray": round(sec_bytes / n_sec, 1),
         "compulsory_bytes_per_ray": 36,
+        "hbm_peak_GBs": HBM_PEAK_GBS,
         "primary_kernel_ms": round(pri_ms, 4),
-        "primary_achieved_GBs": round(algorithmic_bytes(n_pri, pb, ptr_) / (pri_ms * 1e-3) / 1e9, 1) if pri_ms > 0 else 0.0,
-        # the bound that actually binds: the scene is cache-resident, the kernel saturates VALU issue under divergence
-        "issue": issue,
-        "binding": ("valu_issue: the tree and triangles are served from L1/L2 (traffic << algorithmic bytes) and the dominant "
-                    "kernel fills the VALU issue slots at a fraction of the lanes (see `issue`); the HBM figure above is "
-                    "the contract's algorithmic-bytes rate, not a physical limit on this workload"),
-    }
+        "primary_algorithmic_rate_GBs": round(algorithmic_bytes(n_pri, pb, ptr_) / (pri_ms * 1e-3) / 1e9, 1) if pri_ms > 0 else 0.0,
+        "binding": ("valu_issue: the tree and triangles are served from L1 / L2 / Infinity Cache (hbm_measured_frac), and the "
+                    "dominant kernel fills its VALU issue slots at a fraction of the lanes; algorithmic_rate_GBs is the "
+                    "contract's SURVEY 8(d) figure (above the HBM peak because caches serve it), not a roofline position"),
+    })
+    sec["roofline"] = rl
     if want_cpu:
         sec["cpu_baseline"], chk = cpu_closest_hit(scene, po, pd, so, sd, sa, pt_, pi_, st_, si_)
         sec["config"].update(chk)
     return sec, (scene, cam, scene_name, dev)
 
 
-def path_tracing_section(dev, cam, scene_name, pt_spp, rank, world, barrier):
+def path_tracing_section(dev, cam, scene_name, pt_spp, rank, world, barrier, shard="samples"):
     wh = cam.width * cam.height
     pt_spp = max(pt_spp, world)
-    s_begin, s_count = ra.shard_samples(pt_spp, world, rank)
-    acc = torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda")
-    dev.render_pt_dev(cam, acc.data_ptr(), min(s_count, 4), spp_begin=s_begin, seed=1)  # warm-up
+    if shard == "tiles":  # every rank: all samples of its own image tile, one gather (no reduce)
+        tile = ra.shard_tile(cam.width, cam.height, world, rank)
+        s_begin, s_count = 0, pt_spp
+        acc = torch.zeros((tile.height, tile.width, 3), dtype=torch.float32, device="cuda")
+    else:               # every rank: its contiguous sample shard of the whole image, one reduce of the sums
+        tile = None
+        s_begin, s_count = ra.shard_samples(pt_spp, world, rank)
+        acc = torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda")
+    dev.render_tile_dev(cam, tile, acc.data_ptr(), min(s_count, 4), spp_begin=s_begin, seed=1)  # warm-up
     acc.zero_()
     barrier()
     t0 = time.perf_counter()
-    pst = dev.render_pt_dev(cam, acc.data_ptr(), s_count, spp_begin=s_begin, seed=1)
-    reduce_radiance_sums(acc, dst=0)
+    pst = dev.render_tile_dev(cam, tile, acc.data_ptr(), s_count, spp_begin=s_begin, seed=1)
+    if shard == "tiles":
+        torch.cuda.synchronize()
+        acc = gather_tiles(acc, cam.width, cam.height, dst=0)
+    else:
+        reduce_radiance_sums(acc, dst=0)
     barrier()
     pt_elapsed = time.perf_counter() - t0
     pt_stats = torch.tensor([pt_elapsed, float(pst.n_rays), pst.gpu_ms, pst.intersect_ms], dtype=torch.float64,
@@ -254,9 +287,10 @@ def path_tracing_section(dev, cam, scene_name, pt_spp, rank, world, barrier):
         "metric": "path_traced_Msamples_per_s",
         "value": round(wh * pt_spp / pt_elapsed / 1e6, 2),
         "unit": "Msamples/s",
-        "workload": scene_name + " %dx%d, %d spp whole job, maxDepth 20, sample-sharded x%d%s"
-                    % (cam.width, cam.height, pt_spp, world,
-                       ", RCCL reduce of %d MiB fp32 sums" % (wh * 12 >> 20) if world > 1 else ""),
+        "workload": scene_name + " %dx%d, %d spp whole job, maxDepth 20, %s-sharded x%d%s"
+                    % (cam.width, cam.height, pt_spp, "tile" if shard == "tiles" else "sample", world,
+                       (", gather of the tiles" if shard == "tiles" else ", reduce of %d MiB fp32 sums" % (wh * 12 >> 20))
+                       if world > 1 else ""),
         "Mrays_per_s": round(pt_rays / pt_elapsed / 1e6, 2),
         "rays_per_sample": round(pt_rays / (wh * pt_spp), 3),
         "seconds": round(pt_elapsed, 4),
@@ -273,6 +307,9 @@ def main():
     ap.add_argument("--pt-spp", type=int, default=4096,
                     help="spp of the path-tracing section, whole job (BASELINE.json configs[2]: 1024x1024 x 4096 spp)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--pt-shard", choices=("samples", "tiles"), default="samples",
+                    help="how the path-tracing section shards over the ranks: contiguous sample shards + one reduce of the "
+                         "radiance sums (default, BASELINE.json configs[2]) or image tiles + one gather")
     ap.add_argument("--workload", choices=("all", "cornell", "mesh1m", "fog"), default="all",
                     help="all = the Cornell headline + path tracing, then the mesh1m and fog sections; one name = that "
                          "section alone as the top level (what profiles/ are taken from): cornell = BASELINE.json "
@@ -327,11 +364,12 @@ def main():
     if "cpu_baseline" in head:
         out["cpu_baseline"] = head["cpu_baseline"]
     pt = path_tracing_section(dev, cam, scene_name, args.pt_spp if first == "cornell" else max(args.pt_spp // 8, world),
-                              rank, world, barrier)
+                              rank, world, barrier, args.pt_shard)
     if rank == 0:
         out["path_tracing"] = pt
-        if want_cpu and first == "cornell":
-            out["path_tracing"]["cpu_baseline"] = cpu_path_tracing(scene, cam)
+        if want_cpu:
+            out["path_tracing"]["cpu_baseline"] = cpu_path_tracing(scene, cam, 512 if first == "cornell" else 256,
+                                                                   64 if first == "cornell" else 16)
     dev.close()
     scene.close()
     if args.workload == "all":
@@ -341,9 +379,12 @@ def main():
             # fog: configs[4], the medium's path tracing (distance + phase sampling inside the wavefront loop);
             # mesh1m: the metric names path-traced samples/s on the 1 M-triangle mesh too
             if w in ("fog", "mesh1m"):
-                fpt = path_tracing_section(dev, cam, scene_name, max(args.pt_spp // 8, world), rank, world, barrier)
+                fpt = path_tracing_section(dev, cam, scene_name, max(args.pt_spp // 8, world), rank, world, barrier,
+                                           args.pt_shard)
                 if rank == 0:
                     sec["path_tracing"] = fpt
+                    if want_cpu:
+                        sec["path_tracing"]["cpu_baseline"] = cpu_path_tracing(scene, cam, 256, 16)
             dev.close()
             scene.close()
             if rank == 0:
@@ -376,10 +417,19 @@ def cpu_closest_hit(scene, po, pd, so, sd, sa, pt_, pi_, st_, si_):
     t1c, i1c = oracle.intersect(o1, d1, None, 0, threads=threads)
     t2c, i2c = oracle.intersect(o2, d2, a2, 2, threads=threads)
     dt = time.perf_counter() - t0
+    # the one-thread figure SURVEY.md 8(d) asks for, on the head of the same sample (same 1 : 3 mix)
+    m1, m2 = n1 // 16, n2 // 16
+    t0 = time.perf_counter()
+    oracle.intersect(o1[:, :m1].copy(), d1[:, :m1].copy(), None, 0, threads=1)
+    oracle.intersect(o2[:, :m2].copy(), d2[:, :m2].copy(), a2[:m2].copy(), 2, threads=1)
+    dt1 = time.perf_counter() - t0
     oracle.close()
     hit = {"value": round((n1 + n2) / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "one_thread_value": round((m1 + m2) / dt1 / 1e6, 3),
            "sample": "first %d camera + first %d secondary rays of the same batch, reference traversal order "
-                     "(both children, no pruning), OpenMP over rays, %.1f s wall" % (n1, n2, dt)}
+                     "(both children, no pruning), OpenMP over rays, %.1f s wall; one thread: the first %d + %d of them, "
+                     "%.1f s" % (n1, n2, dt, m1, m2, dt1),
+           "note": CPU_NOTE}
     # ---- the GPU's answers on the same rays (the timed passes' outputs) against the oracle's ---------------
     mism, rel = 0, 0.0
     for tg, ig, tc, ic in ((pt_[:n1].cpu().numpy(), pi_[:n1].cpu().numpy(), t1c, i1c),
@@ -394,21 +444,38 @@ def cpu_closest_hit(scene, po, pd, so, sd, sa, pt_, pi_, st_, si_):
     return hit, chk
 
 
-def cpu_path_tracing(scene, cam):
-    """BASELINE.json configs[0]: the scene at 512x512 x 64 spp (same field of view) through the oracle's restatement
-    of the reference's CPU path tracer, OpenMP over pixels."""
+CPU_NOTE = ("kind 'port': oracle/oracle.cpp, this repository's restatement of the reference algorithm. The reference's own "
+            ".cpp files cannot be built here without stand-in headers (DESIGN.md 3), so the +-10 % speed equivalence "
+            "SURVEY.md 8(d) wanted between port and compiled reference cannot be shown; SURVEY.md 6 measured the compiled "
+            "reference (with shims, another host) at 0.053 Msamples/s/core and 0.47-0.69 Mrays/s/core")
+
+
+def cpu_path_tracing(scene, cam, res=512, spp=64):
+    """The scene at res x res x spp (same field of view; 512^2 x 64 = BASELINE.json configs[0]) through the oracle's
+    restatement of the reference's CPU path tracer, OpenMP over pixels; plus a one-thread figure on a 64^2 image."""
     threads = min(16, os.cpu_count() or 1)
     oracle = _oracle(scene)
-    res = 512
-    sight = max(1, int(cam.sight_dist) * res // int(cam.width))
-    small = ra.make_camera(res, res, sight, position=tuple(cam.position), focus=tuple(cam.focus), up=tuple(cam.up))
+
+    def view(r):
+        sight = max(1, int(cam.sight_dist) * r // int(cam.width))
+        return ra.make_camera(r, r, sight, position=tuple(cam.position), focus=tuple(cam.focus), up=tuple(cam.up)), sight
+
+    small, sight = view(res)
     t0 = time.perf_counter()
-    oracle.render(small, 64, seed=1, threads=threads)
+    oracle.render(small, spp, seed=1, threads=threads)
     dt = time.perf_counter() - t0
+    tiny, _ = view(64)
+    spp1 = max(1, spp // 2)
+    t0 = time.perf_counter()
+    oracle.render(tiny, spp1, seed=1, threads=1)
+    dt1 = time.perf_counter() - t0
     oracle.close()
-    return {"value": round(res * res * 64 / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": "same scene and view at %dx%d (sightDist %d) x 64 spp = BASELINE.json configs[0], OpenMP over "
-                      "pixels, %.1f s wall" % (res, res, sight, dt)}
+    return {"value": round(res * res * spp / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "one_thread_value": round(64 * 64 * spp1 / dt1 / 1e6, 4),
+            "sample": "same scene and view at %dx%d (sightDist %d) x %d spp%s, OpenMP over pixels, %.1f s wall; one thread: "
+                      "64x64 x %d spp, %.1f s" % (res, res, sight, spp, " = BASELINE.json configs[0]" if (res, spp) == (512, 64)
+                                                  else "", dt, spp1, dt1),
+            "note": CPU_NOTE}
 
 
 if __name__ == "__main__":

@@ -174,6 +174,18 @@ typedef struct MirtRenderParams {
     uint32_t spp_per_launch; /* samples per pixel kept in flight per wavefront; 0 = auto     */
 } MirtRenderParams;
 
+/* A pixel window of the image (image tiles as a sharding axis: the north star's "samples-per-pixel and image tiles
+ * shard across the GPUs"). Row 0 = top, like the image. No counterpart in the reference, which always renders the
+ * whole image (PathTracer.cpp:17-18). */
+typedef struct MirtTile {
+    int32_t x0, y0;          /* top-left pixel of the window in the full image                 */
+    int32_t width, height;   /* window size; x0 + width <= camera.width, y0 + height <= camera.height */
+} MirtTile;
+
+/* how mirt_render_pt_multi_shard / mirt_render_pttest_multi_shard cut the work over the contexts */
+#define MIRT_SHARD_SAMPLES 0  /* contiguous sample-index shards of the whole image + one sum reduce */
+#define MIRT_SHARD_TILES   1  /* every context renders ALL samples of its own tile (mirt_shard_tile) + one gather, no reduce */
+
 typedef struct MirtRenderStats {
     uint64_t n_samples;      /* camera paths started                                         */
     uint64_t n_rays;         /* closest-hit queries issued (primary + secondary)             */
@@ -290,6 +302,26 @@ int mirt_render_pttest(MirtContext* ctx, const MirtRenderParams* params, float* 
 int mirt_render_pttest_dev(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
                            MirtRenderStats* stats /* may be NULL */);
 
+/* The same two integrators restricted to a pixel window (image-tile sharding). rgb_sum: DEVICE float[tile->height *
+ * tile->width * 3], pixel-major inside the WINDOW (local row 0 = image row tile->y0); the call ADDS into it like
+ * mirt_render_pt_dev. Camera rays, RNG streams (keyed by the pixel of the full image and the global sample index)
+ * and the vignetting term are the full frame's, and samples are added to the accumulator one by one in sample order,
+ * so tiles rendered separately and put side by side are BIT-EQUAL to the full-frame render from the same (zeroed)
+ * accumulator, whatever the tile sizes and spp_per_launch (tests/test_gpu_tiles.py). tile == NULL: the whole image.
+ * stats->n_samples counts the window's paths. No counterpart in the reference (PathTracer.cpp:17-18 loops over
+ * every pixel); for callers that shard an image over GPUs by tiles instead of by samples.                          */
+int mirt_render_pt_tile_dev(MirtContext* ctx, const MirtRenderParams* params, const MirtTile* tile, float* rgb_sum,
+                            MirtRenderStats* stats /* may be NULL */);
+int mirt_render_pttest_tile_dev(MirtContext* ctx, const MirtRenderParams* params, const MirtTile* tile, float* rgb_sum,
+                                MirtRenderStats* stats /* may be NULL */);
+/* The tiling MIRT_SHARD_TILES uses, for callers that run one process per GPU and gather the tiles themselves
+ * (renderer_amd.shard_tiles): tile k of n_shards of a width x height image. The image is cut into a gx x gy grid
+ * (gy = the largest divisor of n_shards with gy * gy <= n_shards, gx = n_shards / gy; k = row * gx + column), in steps
+ * of 16 pixels where the image allows it (the camera pass walks a window in 16 x 16 blocks), the first cuts one step
+ * wider when it does not divide. A tile may be empty (width or height 0) when there are more shards than pixels.
+ * Returns MIRT_E_INVALID for non-positive sizes or k outside [0, n_shards).                                         */
+int mirt_shard_tile(int32_t width, int32_t height, int32_t n_shards, int32_t k, MirtTile* out);
+
 /* --- several GPUs -----------------------------------------------------------------------------
  * The same seam (MCRenderer::renderPixels as Renderer::render calls it, MCRenderer.h:114-117, Renderer.cpp:46-50) over
  * n_ctx contexts, normally one per GPU (several on one device work too). The reference has no counterpart: its only
@@ -305,6 +337,17 @@ int mirt_render_pt_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderPa
                          MirtRenderStats* stats /* may be NULL */);
 int mirt_render_pttest_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, float* rgb_sum,
                              MirtRenderStats* stats /* may be NULL */);
+/* The same with the sharding axis chosen by the caller: shard = MIRT_SHARD_SAMPLES is mirt_render_pt_multi /
+ * mirt_render_pttest_multi; shard = MIRT_SHARD_TILES gives context k the tile mirt_shard_tile(width, height, n_ctx, k)
+ * and ALL the call's samples, renders every tile into its own device accumulator (mirt_render_pt_tile_dev) from its
+ * own host thread, and GATHERS the tiles into the host image rgb_sum (overwritten): no reduce, and the image is
+ * bit-equal to the one-context image. The scene is replicated either way. stats as above.                          */
+int mirt_render_pt_multi_shard(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, int shard,
+                               float* rgb_sum, MirtRenderStats* stats /* may be NULL */);
+int mirt_render_pttest_multi_shard(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, int shard,
+                                   float* rgb_sum, MirtRenderStats* stats /* may be NULL */);
+/* the device index a context was created on (mirt_create's argument); -1 for NULL */
+int mirt_context_device(const MirtContext* ctx);
 /* number of HIP devices (0 when there is none; never an error) */
 int mirt_device_count(void);
 

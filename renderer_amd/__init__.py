@@ -37,6 +37,14 @@ class RenderParams(C.Structure):
                 ("max_depth", C.c_uint32), ("seed", C.c_uint32), ("spp_per_launch", C.c_uint32)]
 
 
+class Tile(C.Structure):
+    """MirtTile (include/mirt.h): a pixel window of the image, row 0 = top"""
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+SHARD_SAMPLES, SHARD_TILES = 0, 1  # MIRT_SHARD_*
+
+
 class RenderStats(C.Structure):
     _fields_ = [("n_samples", C.c_uint64), ("n_rays", C.c_uint64), ("gpu_ms", C.c_double),
                 ("intersect_ms", C.c_double), ("n_shadow_rays", C.c_uint64)]
@@ -89,6 +97,8 @@ def texture_structs(textures):
 MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_scene", "mirt_scene_serial", "mirt_intersect",
                 "mirt_intersect_dev", "mirt_intersect_noalloc_dev", "mirt_visibility", "mirt_visibility_dev", "mirt_fast_tree", "mirt_intersect_count_dev", "mirt_intersect_audit_dev", "mirt_generate_rays_dev", "mirt_render_pt",
                 "mirt_render_pt_dev", "mirt_render_pttest", "mirt_render_pttest_dev", "mirt_render_pt_multi", "mirt_render_pttest_multi", "mirt_device_count",
+                "mirt_render_pt_tile_dev", "mirt_render_pttest_tile_dev", "mirt_shard_tile", "mirt_render_pt_multi_shard",
+                "mirt_render_pttest_multi_shard", "mirt_context_device",
                 "mirt_capture_rays_dev", "mirt_device_info"]
 MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_set_textures", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
@@ -148,6 +158,14 @@ def lib():
         L.mirt_render_pt_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RenderParams), C.c_void_p,
                                            C.POINTER(RenderStats)]
         L.mirt_render_pttest_multi.argtypes = L.mirt_render_pt_multi.argtypes
+        L.mirt_render_pt_tile_dev.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Tile), C.c_void_p,
+                                              C.POINTER(RenderStats)]
+        L.mirt_render_pttest_tile_dev.argtypes = L.mirt_render_pt_tile_dev.argtypes
+        L.mirt_shard_tile.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Tile)]
+        L.mirt_render_pt_multi_shard.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RenderParams), C.c_int, C.c_void_p,
+                                                 C.POINTER(RenderStats)]
+        L.mirt_render_pttest_multi_shard.argtypes = L.mirt_render_pt_multi_shard.argtypes
+        L.mirt_context_device.argtypes = [C.c_void_p]
         L.mirt_device_count.argtypes = []
         L.mirth_set_devices.argtypes = [C.c_void_p, C.c_int32]
         L.mirt_capture_rays_dev.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.c_uint32,
@@ -512,6 +530,19 @@ class Device:
         self._check(lib().mirt_render_pt_dev(self.ctx, C.byref(p), rgb_sum_ptr, C.byref(st)))
         return st
 
+    def render_tile_dev(self, cam, tile, rgb_sum_ptr, spp_count, spp_begin=0, max_depth=20, seed=1, spp_per_launch=0,
+                        pttest=False):
+        """mirt_render_pt_tile_dev / mirt_render_pttest_tile_dev: ADDS the window's samples into the DEVICE buffer
+        float[tile.height * tile.width * 3]; tile None = the whole image."""
+        p = RenderParams(cam, spp_begin, spp_count, max_depth, seed, spp_per_launch)
+        st = RenderStats()
+        fn = lib().mirt_render_pttest_tile_dev if pttest else lib().mirt_render_pt_tile_dev
+        self._check(fn(self.ctx, C.byref(p), None if tile is None else C.byref(tile), rgb_sum_ptr, C.byref(st)))
+        return st
+
+    def device_index(self):
+        return lib().mirt_context_device(self.ctx)
+
     def capture_rays_dev(self, cam, spp_count, depth_lo, depth_hi, o_ptr, d_ptr, aux_ptr, capacity,
                          spp_begin=0, max_depth=20, seed=1):
         p = RenderParams(cam, spp_begin, spp_count, max_depth, seed, 0)
@@ -521,15 +552,21 @@ class Device:
         return n.value
 
 
-def render_pt_multi(devices, cam, spp_count, spp_begin=0, max_depth=20, seed=1, spp_per_launch=0, pttest=False):
+def render_pt_multi(devices, cam, spp_count, spp_begin=0, max_depth=20, seed=1, spp_per_launch=0, pttest=False,
+                    shard=None):
     """mirt_render_pt_multi over a list of Device objects (each holding the scene): contiguous sample shards, one
-    reduce on devices[0]'s GPU. Returns (rgb_sum [H, W, 3] float32 on the host, RenderStats)."""
+    reduce on devices[0]'s GPU; shard=SHARD_TILES (mirt_render_pt_multi_shard): one image tile per device, all
+    samples, gathered. Returns (rgb_sum [H, W, 3] float32 on the host, RenderStats)."""
     p = RenderParams(cam, spp_begin, spp_count, max_depth, seed, spp_per_launch)
     img = np.zeros((cam.height, cam.width, 3), np.float32)
     st = RenderStats()
     arr = (C.c_void_p * len(devices))(*[d.ctx for d in devices])
-    fn = lib().mirt_render_pttest_multi if pttest else lib().mirt_render_pt_multi
-    rc = fn(arr, len(devices), C.byref(p), _ptr(img), C.byref(st))
+    if shard is None:
+        fn = lib().mirt_render_pttest_multi if pttest else lib().mirt_render_pt_multi
+        rc = fn(arr, len(devices), C.byref(p), _ptr(img), C.byref(st))
+    else:
+        fn = lib().mirt_render_pttest_multi_shard if pttest else lib().mirt_render_pt_multi_shard
+        rc = fn(arr, len(devices), C.byref(p), int(shard), _ptr(img), C.byref(st))
     if rc != 0:
         raise MirtError("mirt error %d: %s" % (rc, lib().mirt_last_error(devices[0].ctx).decode()))
     return img, st
@@ -549,6 +586,14 @@ def make_camera(width, height, sight_dist, position=(0, 0, 2), focus=(0, 0, 0), 
     c.focus[:] = focus
     c.up[:] = up
     return c
+
+
+def shard_tile(width, height, world_size, rank):
+    """mirt_shard_tile: the image tile of rank `rank` when an image is sharded by tiles (host arithmetic, no GPU)."""
+    t = Tile()
+    if lib().mirt_shard_tile(width, height, world_size, rank, C.byref(t)) != 0:
+        raise MirtError("mirt_shard_tile: bad arguments")
+    return t
 
 
 def shard_samples(spp_total, world_size, rank):

@@ -1588,11 +1588,18 @@ int mirt_visibility(MirtContext* ctx, const float* origins, const float* directi
 }  // extern "C"
 
 // ---- camera + wavefront loop ------------------------------------------------------------------------
-static int make_camera(MirtContext* ctx, const MirtCamera* c, DevCamera* out) {
+static int make_camera(MirtContext* ctx, const MirtCamera* c, DevCamera* out, const MirtTile* tile = nullptr) {
     if (!c || c->width <= 0 || c->height <= 0)
         return fail(ctx, MIRT_E_INVALID, "camera: width/height must be positive");
     if ((uint64_t)c->width * (uint64_t)c->height > (1ull << 28))
         return fail(ctx, MIRT_E_LIMIT, "camera: more than 2^28 pixels");
+    if (tile && (tile->x0 < 0 || tile->y0 < 0 || tile->width <= 0 || tile->height <= 0 ||
+                 (int64_t)tile->x0 + tile->width > c->width || (int64_t)tile->y0 + tile->height > c->height))
+        return fail(ctx, MIRT_E_INVALID, "tile: the pixel window must be non-empty and lie inside the image");
+    out->tx0 = tile ? tile->x0 : 0;
+    out->ty0 = tile ? tile->y0 : 0;
+    out->tw = tile ? tile->width : c->width;
+    out->th = tile ? tile->height : c->height;
     // Camera.cpp:6-10
     h3 pos{c->position[0], c->position[1], c->position[2]};
     h3 front = hnormalize(hsub(h3{c->focus[0], c->focus[1], c->focus[2]}, pos));
@@ -1717,7 +1724,7 @@ static int ensure_counts(MirtContext* ctx, hipStream_t st, size_t words) {
 static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRenderParams* prm,
                          uint32_t s0, uint32_t S, float* rgb_sum, Capture* cap, uint64_t* n_rays,
                          size_t* ev_used, bool nee = false, uint64_t* n_shadow = nullptr) {
-    const uint32_t wh = (uint32_t)cam.width * (uint32_t)cam.height;
+    const uint32_t wh = (uint32_t)cam.tw * (uint32_t)cam.th;  // pixels of the window being rendered
     const uint32_t P = wh * S;
     hipStream_t st = ctx->stream;
     const int B = 256;
@@ -1843,7 +1850,7 @@ static uint32_t chain_cut(uint32_t max_depth) {
 
 static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderParams* prm, uint32_t S, float* rgb_sum,
                        uint64_t* n_rays, size_t* ev_used, MirtRenderStats* stats) {
-    const uint32_t wh = (uint32_t)cam.width * (uint32_t)cam.height;
+    const uint32_t wh = (uint32_t)cam.tw * (uint32_t)cam.th;  // pixels of the window being rendered
     const uint32_t cut = chain_cut(prm->max_depth);
     const int gens = (int)(prm->max_depth / cut) + 1;
     const uint32_t n_wf = (prm->spp_count + S - 1) / S;
@@ -1961,7 +1968,7 @@ static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderP
 }
 
 static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* rgb_sum_dev, Capture* cap,
-                         MirtRenderStats* stats, bool nee = false) {
+                         MirtRenderStats* stats, bool nee = false, const MirtTile* tile = nullptr) {
     if (!ctx) return MIRT_E_INVALID;
     if (!ctx->has_scene) return fail(ctx, MIRT_E_NO_SCENE, "render: no scene uploaded");
     if (!prm) return fail(ctx, MIRT_E_INVALID, "render: params is NULL");
@@ -1972,10 +1979,10 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     // a path carries its depth in the top byte of its RNG counter word (pt_kernels.h, CTR_DEPTH_SHIFT)
     if (prm->max_depth > 250) return fail(ctx, MIRT_E_LIMIT, "render: max_depth above 250");
     DevCamera cam;
-    int rc = make_camera(ctx, &prm->camera, &cam);
+    int rc = make_camera(ctx, &prm->camera, &cam, tile);
     if (rc != MIRT_OK) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const uint64_t wh = (uint64_t)cam.width * cam.height;
+    const uint64_t wh = (uint64_t)cam.tw * cam.th;  // pixels of the window being rendered
     uint32_t S = prm->spp_per_launch;
     // plain path tracing over several wavefronts: chained (run_chained); MIRT_CHAIN=0 switches it off (A/B)
     static const bool chain_on = !getenv("MIRT_CHAIN") || atoi(getenv("MIRT_CHAIN")) != 0;
@@ -2133,6 +2140,43 @@ int mirt_render_pttest(MirtContext* ctx, const MirtRenderParams* params, float* 
     return rc;
 }
 
+int mirt_render_pt_tile_dev(MirtContext* ctx, const MirtRenderParams* params, const MirtTile* tile, float* rgb_sum,
+                            MirtRenderStats* stats) {
+    if (stats) *stats = MirtRenderStats{};
+    if (ctx && !rgb_sum) return fail(ctx, MIRT_E_INVALID, "render: rgb_sum is NULL");
+    return render_common(ctx, params, rgb_sum, nullptr, stats, false, tile);
+}
+
+int mirt_render_pttest_tile_dev(MirtContext* ctx, const MirtRenderParams* params, const MirtTile* tile, float* rgb_sum,
+                                MirtRenderStats* stats) {
+    if (stats) *stats = MirtRenderStats{};
+    if (ctx && !rgb_sum) return fail(ctx, MIRT_E_INVALID, "render_pttest: rgb_sum is NULL");
+    return render_common(ctx, params, rgb_sum, nullptr, stats, true, tile);
+}
+
+// [begin, begin + count) of part `idx` of `len` cut into `parts`: in steps of 16 where len allows it
+static void cut_axis(int len, int parts, int idx, int* begin, int* count) {
+    const int step = (len % 16 == 0 && len / 16 >= parts) ? 16 : 1;
+    const int units = len / step, base = units / parts, rem = units % parts;
+    *begin = (idx * base + std::min(idx, rem)) * step;
+    *count = (base + (idx < rem ? 1 : 0)) * step;
+}
+
+int mirt_shard_tile(int32_t width, int32_t height, int32_t n_shards, int32_t k, MirtTile* out) {
+    if (!out || width <= 0 || height <= 0 || n_shards <= 0 || k < 0 || k >= n_shards) return MIRT_E_INVALID;
+    int gy = 1;
+    for (int d = 1; d * d <= n_shards; d++)
+        if (n_shards % d == 0) gy = d;
+    const int gx = n_shards / gy;
+    int x0, w, y0, h;
+    cut_axis(width, gx, k % gx, &x0, &w);
+    cut_axis(height, gy, k / gx, &y0, &h);
+    *out = MirtTile{x0, y0, w, h};
+    return MIRT_OK;
+}
+
+int mirt_context_device(const MirtContext* ctx) { return ctx ? ctx->device : -1; }
+
 int mirt_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
@@ -2141,11 +2185,13 @@ int mirt_device_count(void) {
 // Sample shards over several contexts + one reduce (include/mirt.h). One host thread per context: a render call
 // blocks on its own stream now and then (live-path counts), and the contexts' devices run independently.
 static int render_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, float* rgb_sum,
-                        MirtRenderStats* stats, bool nee) {
+                        MirtRenderStats* stats, bool nee, int shard = MIRT_SHARD_SAMPLES) {
     if (stats) *stats = MirtRenderStats{};
     if (!ctxs || n_ctx <= 0 || !ctxs[0]) return MIRT_E_INVALID;
     MirtContext* c0 = ctxs[0];
     if (!params || !rgb_sum) return fail(c0, MIRT_E_INVALID, "render_multi: NULL argument");
+    if (shard != MIRT_SHARD_SAMPLES && shard != MIRT_SHARD_TILES) return fail(c0, MIRT_E_INVALID, "render_multi: unknown shard mode");
+    const bool tiles = shard == MIRT_SHARD_TILES;
     for (int k = 0; k < n_ctx; k++) {
         if (!ctxs[k]) return fail(c0, MIRT_E_INVALID, "render_multi: NULL context");
         for (int j = 0; j < k; j++)
@@ -2159,14 +2205,23 @@ static int render_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderPar
     struct Shard {
         MirtRenderParams prm;
         MirtRenderStats st{};
+        MirtTile tile{};
         float* acc = nullptr;
+        size_t bytes = 0;
         int rc = MIRT_OK;
     };
     std::vector<Shard> sh(n_ctx);
     const uint32_t base = params->spp_count / (uint32_t)n_ctx, rem = params->spp_count % (uint32_t)n_ctx;
     uint32_t begin = params->spp_begin;
-    for (int k = 0; k < n_ctx; k++) {  // contiguous shards; the same split as renderer_amd.shard_samples
+    for (int k = 0; k < n_ctx; k++) {
         sh[k].prm = *params;
+        sh[k].bytes = bytes;
+        if (tiles) {  // every context: all samples of its own tile
+            mirt_shard_tile(params->camera.width, params->camera.height, n_ctx, k, &sh[k].tile);
+            sh[k].bytes = (size_t)sh[k].tile.width * sh[k].tile.height * 3 * sizeof(float);
+            continue;
+        }
+        // contiguous sample shards; the same split as renderer_amd.shard_samples
         sh[k].prm.spp_begin = begin;
         sh[k].prm.spp_count = base + ((uint32_t)k < rem ? 1u : 0u);
         begin += sh[k].prm.spp_count;
@@ -2174,9 +2229,10 @@ static int render_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderPar
     auto work = [&](int k) {
         MirtContext* ctx = ctxs[k];
         Shard& S = sh[k];
+        if (S.bytes == 0) return;  // more contexts than pixels: an empty tile
         hipError_t e = hipSetDevice(ctx->device);
-        if (e == hipSuccess) e = hipMalloc(&S.acc, bytes);
-        if (e == hipSuccess) e = hipMemsetAsync(S.acc, 0, bytes, ctx->stream);
+        if (e == hipSuccess) e = hipMalloc(&S.acc, S.bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(S.acc, 0, S.bytes, ctx->stream);
         if (e != hipSuccess) {
             S.rc = fail(ctx, MIRT_E_HIP, std::string("render_multi: ") + hipGetErrorString(e));
             return;
@@ -2186,7 +2242,7 @@ static int render_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderPar
             if (e != hipSuccess) S.rc = fail(ctx, MIRT_E_HIP, hipGetErrorString(e));
             return;
         }
-        S.rc = render_common(ctx, &S.prm, S.acc, nullptr, &S.st, nee);
+        S.rc = render_common(ctx, &S.prm, S.acc, nullptr, &S.st, nee, tiles ? &S.tile : nullptr);
     };
     std::vector<std::thread> threads;
     for (int k = 1; k < n_ctx; k++) threads.emplace_back(work, k);
@@ -2198,11 +2254,30 @@ static int render_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderPar
             rc = sh[k].rc;
             if (k) c0->err = "render_multi: context " + std::to_string(k) + ": " + ctxs[k]->err;
         }
-    // reduce on context 0's device, in context order (deterministic): peer copy into a staging buffer, then add
     float* tmp = nullptr;
-    hipError_t e = hipSetDevice(c0->device);
-    if (rc == MIRT_OK && n_ctx > 1 && e == hipSuccess) e = hipMalloc(&tmp, bytes);
-    for (int k = 1; k < n_ctx && rc == MIRT_OK && e == hipSuccess; k++) {
+    hipError_t e = hipSuccess;
+    if (tiles && rc == MIRT_OK) {
+        // gather: every tile's rows into their place in the host image (no arithmetic: the image is bit-equal to the
+        // one-context render)
+        std::vector<float> stage;
+        const size_t W = (size_t)params->camera.width;
+        for (int k = 0; k < n_ctx && e == hipSuccess; k++) {
+            const Shard& S = sh[k];
+            if (!S.acc) continue;
+            stage.resize(S.bytes / sizeof(float));
+            e = hipSetDevice(ctxs[k]->device);
+            if (e == hipSuccess) e = hipMemcpy(stage.data(), S.acc, S.bytes, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) break;
+            const size_t row = (size_t)S.tile.width * 3;
+            for (int y = 0; y < S.tile.height; y++)
+                memcpy(rgb_sum + ((size_t)(S.tile.y0 + y) * W + (size_t)S.tile.x0) * 3, stage.data() + (size_t)y * row, row * sizeof(float));
+        }
+        if (e != hipSuccess) rc = fail(c0, MIRT_E_HIP, std::string("render_multi: gather: ") + hipGetErrorString(e));
+    }
+    // reduce on context 0's device, in context order (deterministic): peer copy into a staging buffer, then add
+    if (!tiles) e = hipSetDevice(c0->device);
+    if (!tiles && rc == MIRT_OK && n_ctx > 1 && e == hipSuccess) e = hipMalloc(&tmp, bytes);
+    for (int k = 1; !tiles && k < n_ctx && rc == MIRT_OK && e == hipSuccess; k++) {
         e = hipMemcpyPeer(tmp, c0->device, sh[k].acc, ctxs[k]->device, bytes);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(k_add, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, c0->stream, sh[0].acc, (const float*)tmp,
@@ -2210,8 +2285,8 @@ static int render_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderPar
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);  // tmp is reused by the next context
     }
-    if (rc == MIRT_OK && e == hipSuccess) e = hipMemcpy(rgb_sum, sh[0].acc, bytes, hipMemcpyDeviceToHost);
-    if (rc == MIRT_OK && e != hipSuccess) rc = fail(c0, MIRT_E_HIP, std::string("render_multi: reduce: ") + hipGetErrorString(e));
+    if (!tiles && rc == MIRT_OK && e == hipSuccess) e = hipMemcpy(rgb_sum, sh[0].acc, bytes, hipMemcpyDeviceToHost);
+    if (!tiles && rc == MIRT_OK && e != hipSuccess) rc = fail(c0, MIRT_E_HIP, std::string("render_multi: reduce: ") + hipGetErrorString(e));
     hipFree(tmp);
     for (int k = 0; k < n_ctx; k++) {
         if (!sh[k].acc) continue;
@@ -2237,6 +2312,16 @@ int mirt_render_pt_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderPa
 int mirt_render_pttest_multi(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, float* rgb_sum,
                              MirtRenderStats* stats) {
     return render_multi(ctxs, n_ctx, params, rgb_sum, stats, true);
+}
+
+int mirt_render_pt_multi_shard(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, int shard,
+                               float* rgb_sum, MirtRenderStats* stats) {
+    return render_multi(ctxs, n_ctx, params, rgb_sum, stats, false, shard);
+}
+
+int mirt_render_pttest_multi_shard(MirtContext* const* ctxs, int n_ctx, const MirtRenderParams* params, int shard,
+                                   float* rgb_sum, MirtRenderStats* stats) {
+    return render_multi(ctxs, n_ctx, params, rgb_sum, stats, true, shard);
 }
 
 int mirt_capture_rays_dev(MirtContext* ctx, const MirtRenderParams* params, uint32_t depth_lo,

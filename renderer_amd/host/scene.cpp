@@ -37,7 +37,11 @@ void IntersectionHIP::init(int device) {
 }
 
 void IntersectionHIP::setDevices(const std::vector<int>& devices) {
-    init(devices.empty() ? 0 : devices[0]);
+    // the service's first context must sit on devices[0]: one created earlier on another device (init(), a previous
+    // setDevices) is replaced, so that batch queries and the reduce run where the caller was told they run
+    const int first = devices.empty() ? 0 : devices[0];
+    if (g_ctx && mirt_context_device(g_ctx) != first) shutdown();
+    init(first);
     for (size_t k = 1; k < g_all.size(); k++) mirt_destroy(g_all[k]);
     g_all.assign(1, g_ctx);
     g_resident = nullptr;  // the new contexts hold no scene yet: the next query / render uploads to all

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Summarises a scripts/profile_gpu.sh output directory into one text file (for profiles/).
 usage: summarize_profile.py gpurun_out/prof_r1 [traffic.json] > profiles/r1_summary.txt
-With a second argument the HBM-side bytes per dispatch of every kernel (FETCH_SIZE doubled as the
-guide prescribes for gfx950 and as the known ray-input byte count confirms, plus WRITE_SIZE) are
-also written as JSON; bench.py reports them as roofline.traffic."""
+With a second argument the HBM-side bytes per dispatch of every kernel are also written as JSON; bench.py reports
+them as roofline.traffic. FETCH_SIZE on gfx950 is TCC_EA0_RDREQ x 64 B: half of the bytes of a wide streaming read
+(one request per 128 B: the guide's x2) but exactly the bytes of a gather of 64-B records (one request per record),
+which is what the traversal kernels mostly issue (profiles/r3_fetch_factor.txt, scripts/experiments/fetch_factor.hip).
+A kernel mixes both shapes, so read bytes are given as a range: read_bytes = raw FETCH_SIZE (every request a 64-B
+record), read_bytes_x2 = twice that (every request a 128-B streaming request; also what the fabric moves if it moves
+whole 128-B lines per request)."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
@@ -12,9 +16,11 @@ def short(name):
     name = re.sub(r"\(.*", "", name).replace("void ", "").replace("mirt::", "")
     return name[:70]
 print("# rocprofv3 summary of: python3 bench.py --steps N --warmup 1 --no-cpu --pt-spp 8 [--workload X] (scripts/profile_gpu.sh), directory %s" % d)
+avg_us = {}
 for f in sorted(glob.glob(os.path.join(d, "kt", "*", "*_kernel_stats.csv")))[-1:]:
     print("\n## kernel trace --stats (per kernel: calls, total ms, average us, % of GPU time)")
     for r in csv.DictReader(open(f)):
+        avg_us[short(r["Name"])] = float(r["AverageNs"]) / 1e3
         if float(r["Percentage"]) < 0.05: continue
         print("%-72s calls %5s total %10.3f ms avg %12.3f us  %6.2f%%" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 agg = defaultdict(lambda: defaultdict(float)); calls = defaultdict(lambda: defaultdict(int)); meta = {}
@@ -39,7 +45,7 @@ for k in sorted(agg):
     if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and (g("TCC_HIT_sum") + g("TCC_MISS_sum")) > 0:
         print("    -> L2 hit rate %.2f%%" % (100 * g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))))
     if g("FETCH_SIZE") is not None:
-        print("    -> HBM-side read  : FETCH_SIZE %.1f KiB raw; x2 gfx950 correction for wide coalesced streams = %.3f MB" % (g("FETCH_SIZE"), 2 * g("FETCH_SIZE") * 1024 / 1e6))
+        print("    -> HBM-side read  : FETCH_SIZE %.1f KiB raw = %.3f MB if every request is a 64-B record gather, %.3f MB if every request is a 128-B streaming request (profiles/r3_fetch_factor.txt)" % (g("FETCH_SIZE"), g("FETCH_SIZE") * 1024 / 1e6, 2 * g("FETCH_SIZE") * 1024 / 1e6))
     if g("WRITE_SIZE") is not None:
         print("    -> HBM-side write : WRITE_SIZE %.1f KiB = %.3f MB" % (g("WRITE_SIZE"), g("WRITE_SIZE") * 1024 / 1e6))
     issue_frac = lanes = l2 = None
@@ -52,12 +58,15 @@ for k in sorted(agg):
     if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and (g("TCC_HIT_sum") + g("TCC_MISS_sum")) > 0:
         l2 = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
     if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
-        traffic[k] = {"read_bytes": 2 * g("FETCH_SIZE") * 1024, "write_bytes": g("WRITE_SIZE") * 1024,
-                      "dispatches": calls[k]["FETCH_SIZE"],
+        traffic[k] = {"read_bytes": g("FETCH_SIZE") * 1024, "read_bytes_x2": 2 * g("FETCH_SIZE") * 1024,
+                      "write_bytes": g("WRITE_SIZE") * 1024,
+                      "dispatches": calls[k]["FETCH_SIZE"], "avg_us": avg_us.get(k),
                       "valu_issue_frac": None if issue_frac is None else round(issue_frac, 4),
                       "lanes_active_of_64": None if lanes is None else round(lanes, 2),
                       "l2_hit_rate": None if l2 is None else round(l2, 4)}
 if len(sys.argv) > 2:
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of scripts/profile_gpu.sh; "
-                         "FETCH_SIZE doubled (gfx950), mean per dispatch", "kernels": traffic},
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* / GRBM_GUI_ACTIVE / TCC_HIT,MISS (separate passes) and "
+                         "--kernel-trace --stats (avg_us) of scripts/profile_gpu.sh; means per dispatch; read_bytes = raw "
+                         "FETCH_SIZE (64-B gathers are counted exactly), read_bytes_x2 = doubled (streaming reads are counted "
+                         "at half): profiles/r3_fetch_factor.txt", "kernels": traffic},
               open(sys.argv[2], "w"), indent=1)

@@ -11,6 +11,17 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The world-size-2 tests run their ranks in fresh processes. Those are forked by multiprocessing's fork server,
+    # which is started HERE, before anything in this process has touched the GPU: a process that holds the GPU must
+    # not exec another program (and the fork server's children are plain forks of a clean interpreter, no exec).
+    import multiprocessing as mp
+    from multiprocessing import forkserver
+
+    try:
+        mp.set_start_method("forkserver")
+    except RuntimeError:
+        pass
+    forkserver.ensure_running()
 
 
 DATA = os.path.join(ROOT, "Data")

@@ -44,3 +44,13 @@ def test_two_rank_sample_sharding_and_reduce(tmp_path, cornell, cornell_oracle, 
     ref, _ = cornell_oracle.render(ra.make_camera(48, 40, 33), spp, seed=5, threads=4)
     # identical up to the fp32 order of the cross-rank sum
     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, ref.max())
+
+
+def test_two_rank_tile_gather(tmp_path, ra):
+    """image tiles: every rank holds its own tile, one gather puts them side by side on rank 0 (no arithmetic)"""
+    import dist_worker
+
+    out = str(tmp_path / "tiles.npy")
+    codes = dist_worker.run_ranks(dist_worker.cpu_tiles_rank, 2, (out,))
+    assert codes == [0, 0], codes
+    assert np.load(out).shape == (37, 50, 3)
