@@ -295,7 +295,10 @@ int mirt_render_pt_dev(MirtContext* ctx, const MirtRenderParams* params, float* 
  * plus one connection to the emission sampler (Scene.cpp:91-98, SceneObject.cpp:137-160) per RANDOM
  * vertex, tested with MCRenderer::testVisibility (one any-hit launch per bounce) and combined with
  * emitter hits by the balance heuristic. No vignetting compensation (the reference applies none
- * there). Scenes that hold a medium are refused (MIRT_E_INVALID). Same buffers / semantics as
+ * there). Inside a homogeneous medium the estimator is the reference's as well: scattering events connect to the
+ * light through the phase function (SceneVPMObject.cpp:239-267), segments decay by the transmittance, and the
+ * distance-sampling density originProb is NOT divided out (PathTracerTest.cpp:70-74 never does), so there the image is
+ * the reference PathTracerTest's, not the path tracer's. Same buffers / semantics as
  * mirt_render_pt / mirt_render_pt_dev; stats->n_shadow_rays counts the visibility queries.      */
 int mirt_render_pttest(MirtContext* ctx, const MirtRenderParams* params, float* rgb_sum,
                        MirtRenderStats* stats /* may be NULL */);

@@ -1182,6 +1182,7 @@ struct Tracer {
             out.directionProb = 1;
             out.contactObject = object;
             out.contactObjectTriangleID = in.intersectObjectTriangleID;
+            out.randomDir = false;  // DEFINITE in all three outcomes (SceneVPMObject.cpp:44, 73, 81)
             if (f.total) {
                 out.direction = f.reflDir;
                 out.insideObject = in.insideObject;
@@ -1211,6 +1212,7 @@ struct Tracer {
             out.color = V3(ph, ph, ph);
             out.insideObject = object;
             out.contactObjectTriangleID = in.intersectObjectTriangleID;
+            out.randomDir = true;  // RANDOM whether the path goes on or ends (SceneVPMObject.cpp:118, 132)
             V3 ds(o.sigma_s[0], o.sigma_s[1], o.sigma_s[2]);
             float albedo = lumY(ds) / lumY(vpmSigmaT(o));
             float rander = rng.genFloat();
@@ -1250,6 +1252,7 @@ struct Tracer {
                 Fresnel f = fresnel(normal, in.direction, current_n, next_n);
                 out.intersectObject = -1;
                 out.originProb = vpmPSurface(o, in.intersectDist);
+                out.randomDir = false;  // DEFINITE in all three outcomes (SceneVPMObject.cpp:171, 200, 209)
                 if (f.total) {
                     out.direction = f.reflDir;
                     out.insideObject = in.insideObject;
@@ -1548,7 +1551,16 @@ struct Tracer {
     // (scaled by max(colour), as the reference does), Material.h:20 (zero) for the refractive ones,
     // SceneEmissiveObject.cpp:21-26
     V3 getBSDF(const PRay& inRay, const PRay& outRay) const {
-        if (outRay.contactObject < 0) return V3(0, 0, 0);  // (no media here; the camera is never a vertex >= 1)
+        if (outRay.contactObject < 0) {
+            // Ray.cpp:21-24: a vertex without a contact object asks its inside object. For a medium that is
+            // SceneVPMObject::getBSDF (SceneVPMObject.cpp:239-246): ds * phase function of the two directions
+            if (outRay.insideObject >= 0 && S.objects[outRay.insideObject].type == ORC_VPM) {
+                const OrcObject& m = S.objects[outRay.insideObject];
+                const float ph = hgValue(m.g, dot(inRay.direction, outRay.direction));
+                return V3(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]) * ph;
+            }
+            return V3(0, 0, 0);  // (the camera is never a vertex >= 1)
+        }
         const OrcObject& o = S.objects[outRay.contactObject];
         if (o.type == ORC_EMISSIVE)
             return dot(contactNormal(outRay), outRay.direction) < 0 ? V3(0, 0, 0) : V3(o.color[0], o.color[1], o.color[2]);
@@ -1586,7 +1598,18 @@ struct Tracer {
     // DiffuseMaterial.cpp:78-86, GlossyMaterial.cpp:58-67, Material.h:18 (1) for refractive objects;
     // an emissive object has no material (0)
     float directionSampleProbDensity(const PRay& inRay, const PRay& outRay) const {
-        if (outRay.contactObject < 0) return 0;
+        if (outRay.contactObject < 0) {
+            // Ray.cpp:35-38 -> SceneVPMObject::getDirectionSampleProbDensity (SceneVPMObject.cpp:257-267)
+            if (outRay.insideObject >= 0 && S.objects[outRay.insideObject].type == ORC_VPM) {
+                if (!outRay.randomDir) return 0;
+                const OrcObject& m = S.objects[outRay.insideObject];
+                LocalFrame lf;
+                lf.buildFromNormal(inRay.direction);
+                const float albedo = lumY(V3(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2])) / lumY(vpmSigmaT(m));
+                return albedo * hgValue(m.g, dot(lf.n, outRay.direction));
+            }
+            return 0;
+        }
         const OrcObject& o = S.objects[outRay.contactObject];
         // DiffuseMaterial.cpp:83, GlossyMaterial.cpp:66: textures at the vertex
         const V3 dcolor = diffuseColor(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin);
@@ -2014,8 +2037,8 @@ void orc_render_pt(const OrcScene* s, const OrcCamera* cam, uint32_t spp_begin, 
 int orc_render_pttest(const OrcScene* s, const OrcCamera* cam, uint32_t spp_begin, uint32_t spp_count,
                       uint32_t max_depth, uint32_t seed, float* rgb_sum, uint64_t* n_rays,
                       uint64_t* n_shadow_rays, int threads) {
-    for (const OrcObject& o : s->objects)
-        if (o.type == ORC_VPM) return -1;  // restated for scenes without media
+    // (scenes with a medium included: PathTracerTest.cpp:70-74 never divides by originProb, so inside a medium its
+    // estimate is not the path tracer's; it is restated as the reference computes it)
     int npix = cam->width * cam->height;
     std::fill(rgb_sum, rgb_sum + 3 * (size_t)npix, 0.f);
     uint64_t total = 0, shadows = 0;

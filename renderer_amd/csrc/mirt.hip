@@ -1768,9 +1768,14 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
             // PathTracerTest: shade writes one shadow ray per RANDOM vertex; the visibility launch and
             // k_connect add the unoccluded contributions before the next bounce touches L again
             uint32_t* n_sh = ctx->d_ns + depth;
-            hipLaunchKernelGGL((k_shade<false, true>), dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur,
-                               n_in, bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth,
-                               ctx->shb, n_sh);
+            if (ctx->has_media)
+                hipLaunchKernelGGL((k_shade<true, true>), dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur,
+                                   n_in, bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth,
+                                   ctx->shb, n_sh);
+            else
+                hipLaunchKernelGGL((k_shade<false, true>), dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur,
+                                   n_in, bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth,
+                                   ctx->shb, n_sh);
             HIPCHK(ctx, hipGetLastError());
             int rcv = launch_visibility(ctx, st, MIRT_MODE_NO_SELF, ctx->shb.o, ctx->shb.d, ctx->shb.ids, ctx->shb.lim,
                                         bound, ctx->shb.stride, ctx->shb.vis, n_sh, ctx->d_wq2 + 3 * depth);
@@ -1999,9 +2004,6 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     }
     S = std::min<uint32_t>(S, std::max<uint32_t>(prm->spp_count, 1));
     if (wh * S > (1ull << 30)) return fail(ctx, MIRT_E_LIMIT, "render: more than 2^30 paths per wavefront");
-    if (nee && ctx->has_media)
-        return fail(ctx, MIRT_E_INVALID, "render_pttest: scenes that hold a medium (MIRT_OBJ_VPM) are not supported "
-                                         "by the light-connection integrator");
     if (nee) S = std::min<uint32_t>(S, (uint32_t)std::max<uint64_t>(1, (1ull << 26) / wh));
     const bool chained = can_chain && prm->spp_count > S;
     if (chained) {

@@ -506,9 +506,14 @@ __device__ __forceinline__ uint32_t connection_key(uint32_t key) { return lowbia
 // vertex's contact object; `d`: direction of the ray that arrived at the vertex (lastRay.direction).
 // Six draws of the connection stream at 6 * vertexIndex: object, triangle, two for the point, two
 // for the emitted direction that the connection overwrites. Returns false when nothing can arrive.
+// `medium` >= 0: the vertex has NO contact object and lies inside that homogeneous medium (a scattering event,
+// SceneVPMObject.cpp:91-137): Ray::getBSDF / getDirectionSampleProbDensity then ask the inside object (Ray.cpp:21-24,
+// 35-38), i.e. SceneVPMObject::getBSDF = ds * phase(d, out) (SceneVPMObject.cpp:239-246) and albedo * phase pdf
+// (:257-267), and there is no cosine at the vertex (PathTracerTest.cpp:112-116). As in the reference, the
+// connection segment itself carries no transmittance.
 __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObject& hob, const TriRec& T, int slot, f3 nn,
                                               f3 pos, f3 d, uint32_t key, uint32_t vertex, f3& out_dir, float& out_dist,
-                                              f3& contrib) {
+                                              f3& contrib, int medium = -1) {
     if (sc.n_lights <= 0) return false;
     const uint32_t ck = connection_key(key);
     uint32_t cc = 6u * vertex;
@@ -544,7 +549,13 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
     f3 bsdf = mk3(0, 0, 0);
     float pdf = 0.f;
     const bool sides = dot3(nn, d) <= 0.f && dot3(nn, odir) >= 0.f;
-    if (hob.type == MIRT_OBJ_DIFFUSE) {
+    if (medium >= 0) {
+        const DevObject mo = sc.objects[medium];
+        const float ph = hg_value(mo.g, dot3(d, odir));
+        const f3 ds = mk3(mo.sigma_s[0], mo.sigma_s[1], mo.sigma_s[2]);
+        bsdf = ds * ph;
+        pdf = (lum_y(ds) / lum_y(sig_t(mo))) * ph;
+    } else if (hob.type == MIRT_OBJ_DIFFUSE) {
         if (sides) bsdf = div3(col, 3.14159265358979f);
         pdf = max3f(col) * cos_pdf(nn, odir, 1.f);  // DiffuseMaterial.cpp:78-86
     } else if (hob.type == MIRT_OBJ_GLOSSY || hob.type == MIRT_OBJ_PHONG) {
@@ -566,7 +577,7 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
     const f3 nl = shading_normal<true>(sc, LT, LV, lslot, y);
     const float cos_at_light = fminf(fmaxf(0.f, fabsf(dot3(nl, ldir))), 1.f);
     if (cos_at_light < 1e-6f) return false;
-    const float cos_to_light = fminf(fmaxf(0.f, fabsf(dot3(nn, odir))), 1.f);
+    const float cos_to_light = medium >= 0 ? 1.f : fminf(fmaxf(0.f, fabsf(dot3(nn, odir))), 1.f);
     const float dir_pdf_w = Lg.origin_prob * dist2 / cos_at_light;
     const float mis = dir_pdf_w / (dir_pdf_w + pdf);
     const f3 lcol = mk3(lob.color[0], lob.color[1], lob.color[2]);
@@ -588,7 +599,8 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
 // reference's `throughput` there (no originProb, no camera cosine, no vignetting compensation), an
 // emitter hit is weighted against the light connection that could have found it, and every RANDOM
 // vertex writes one shadow ray + its pending contribution to `sh` (compacted like the paths); the
-// visibility launch and k_connect finish it. Scenes without media only (checked on the host).
+// visibility launch and k_connect finish it. With VOL the estimator is the reference's inside media too: light
+// connections from scattering events through the phase function, and NO division by originProb (PathTracerTest.cpp:70-74).
 #ifndef MIRT_SHADE_OCTANT
 #define MIRT_SHADE_OCTANT 1
 #endif
@@ -722,8 +734,10 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                 sr.inside = inside;
                 sr.cos_term = false;
                 sr.emitted = false;
+                sr.random = true;  // SceneVPMObject.cpp:7; DEFINITE at the medium's boundary (:44, 73, 81, 171, 200, 209)
                 sr.nn = nn;
                 if (go_in) {
+                    sr.random = false;
                     const float cur_n = inside >= 0 ? refr_coeff(sc.objects[inside]) : 1.f;
                     float factor;
                     bool through, total;
@@ -761,6 +775,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                     }
                 } else if (be_in && out_of_vol) {
                     if (hobj == sobj) {  // leaving through the medium's own boundary
+                        sr.random = false;
                         const int outside = find_inside(sc, pos, d, sobj);
                         const float next_n = outside >= 0 ? refr_coeff(sc.objects[outside]) : 1.f;
                         float factor;
@@ -805,7 +820,9 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                         if (sr.random) {  // PathTracerTest.cpp:59-63
                             f3 cdir, contrib;
                             float cdist;
-                            if (connect_light(sc, ob, T, slot, nn, sr.pos, d, key, depth + 1, cdir, cdist, contrib)) {
+                            // (a vertex without a contact object is a scattering event inside the medium sr.inside)
+                            const int medium = (VOL && sr.contact < 0) ? sr.inside : -1;
+                            if (connect_light(sc, ob, T, slot, nn, sr.pos, d, key, depth + 1, cdir, cdist, contrib, medium)) {
                                 shadow = true;
                                 sh_o = sr.pos;
                                 sh_d = cdir;
@@ -816,15 +833,17 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                         }
                         if (!(len3(sr.nd) < 0.5f)) {  // PathTracerTest.cpp:68-76 (a NaN direction goes on, MCRenderer.cpp:181)
                             lpw = sr.random ? sr.dirProb : -1.f;
-                            float ct = fabsf(dot3(sr.nn, sr.nd));
+                            float ct = 1.f;  // Ray::getCosineTerm (Ray.cpp:71-78): 1 without a contact object / for a medium's boundary
+                            if (!VOL || sr.cos_term) ct = fabsf(dot3(sr.nn, sr.nd));
                             ct = ct > 1e-6f ? ct : 1e-6f;
                             thr = thr * div3(sr.color * ct, sr.dirProb);
-                            if (inside >= 0) {
+                            if (inside >= 0) {  // eyePath[i - 1].getRadianceDecay (PathTracerTest.cpp:72-74); originProb is never divided out there
                                 const DevObject io = sc.objects[inside];
-                                if (io.type == MIRT_OBJ_REFRACTIVE) {
-                                    const float dist = fmaxf(len3(sr.pos - o), 1e-5f);
+                                const float dist = fmaxf(len3(sr.pos - o), 1e-5f);
+                                if (io.type == MIRT_OBJ_REFRACTIVE)
                                     thr = thr * mk3(powf(io.decay[0], dist), powf(io.decay[1], dist), powf(io.decay[2], dist));
-                                }
+                                else if (VOL && io.type == MIRT_OBJ_VPM)
+                                    thr = thr * vpm_transmittance(io, dist);
                             }
                             alive = depth + 1 <= max_depth;
                             no = sr.pos;

@@ -40,6 +40,18 @@ __global__ void __launch_bounds__(256) k_gather32(const Rec* __restrict__ tab, c
     }
     if (acc == 12345.678f) *sink = acc;
 }
+// whole 128-B lines: every lane reads TWO adjacent records (a 128-B aligned pair), n / 2 lanes' worth
+template <int TAG>
+__global__ void __launch_bounds__(256) k_gather128(const Rec* __restrict__ tab, const uint32_t* __restrict__ perm, uint32_t n,
+                                                   float* __restrict__ sink) {
+    float acc = 0.f;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n / 2; i += gridDim.x * blockDim.x) {
+        const Rec* p = tab + (size_t)(perm[i] & ~1u);
+        const Rec r = p[0], q = p[1];
+        acc += (r.a.x + r.b.y) + (r.c.z + r.d.w) + (q.a.x + q.b.y) + (q.c.z + q.d.w);
+    }
+    if (acc == 12345.678f) *sink = acc;
+}
 // control: the guide's calibrated shape, 16 B per lane, consecutive lanes consecutive addresses
 template <int TAG>
 __global__ void __launch_bounds__(256) k_stream(const float4* __restrict__ tab, size_t n16, float* __restrict__ sink) {
@@ -85,6 +97,7 @@ static void run_case(const char* what, size_t table_bytes, float* sink) {
     };
     timed([&] { hipLaunchKernelGGL((k_gather64<TAG>), grid, block, 0, 0, tab, perm, n, sink); }, "gather 64 B records (4 x dwordx4)", (double)n * 64);
     timed([&] { hipLaunchKernelGGL((k_gather32<TAG>), grid, block, 0, 0, tab, perm, n, sink); }, "gather 32 B of each record", (double)n * 32);
+    timed([&] { hipLaunchKernelGGL((k_gather128<TAG>), grid, block, 0, 0, tab, perm, n, sink); }, "gather n/2 aligned 128 B pairs", (double)(n / 2) * 128);
     timed([&] { hipLaunchKernelGGL((k_stream<TAG>), grid, block, 0, 0, (const float4*)tab, (size_t)n * 4, sink); }, "stream, 16 B per lane", (double)n * 64);
     CHK(hipFree(tab));
     CHK(hipFree(perm));

@@ -201,7 +201,7 @@ class OracleScene:
         rc = lib().orc_render_pttest(self.h, C.byref(oc), spp_begin, spp_count, max_depth, seed, _p(img), C.byref(nr),
                                      C.byref(ns), threads)
         if rc != 0:
-            raise RuntimeError("orc_render_pttest: scenes with a medium are not restated")
+            raise RuntimeError("orc_render_pttest failed (%d)" % rc)
         return img, nr.value, ns.value
 
     def trace_path(self, cam, pixel, sample, max_depth=20, seed=1, cap=64):

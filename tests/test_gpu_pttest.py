@@ -89,11 +89,21 @@ def test_pttest_determinism_sharding_depth(gpu, cornell, cornell_oracle, ra):
     assert st.n_rays == 0 and not g.any()
 
 
-def test_pttest_refuses_media(gpu, ra):
+def test_pttest_in_media_parity(gpu, ra, orc):
+    """PathTracerTest inside a homogeneous medium, as the reference computes it (PathTracerTest.cpp:20-135 with
+    SceneVPMObject.cpp:239-267): connections from scattering events through the phase function, transmittance along
+    the eye segments, originProb never divided out. Same-stream parity with the oracle's restatement on BallsInFog."""
     s = ra.HostScene.load_config(os.path.join(ROOT, "Data", "Config_Fog128.xml"))
+    S = orc.OracleScene(s.raw())
     gpu.upload(s.describe())
-    with pytest.raises(ra.MirtError, match="medium"):
-        gpu.render_pttest(s.camera(), 1)
+    g, c = _parity(gpu, S, s.camera(), 24, same_tol=0.05)
+    assert g.sum() > 0
+    # determinism and sample sharding hold there too
+    a, _ = gpu.render_pttest(s.camera(), 6, seed=3)
+    lo, _ = gpu.render_pttest(s.camera(), 2, spp_begin=0, seed=3)
+    hi, _ = gpu.render_pttest(s.camera(), 4, spp_begin=2, seed=3)
+    assert np.abs((lo + hi) - a).max() <= 1e-5 * max(1.0, a.max())
+    S.close()
     s.close()
 
 

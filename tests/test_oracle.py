@@ -322,6 +322,27 @@ def test_medium_known_answers(orc, ra):
     s.close()
 
 
+def test_pttest_in_medium_known_answer(orc, ra):
+    """PathTracerTest.cpp:34-74 inside a purely absorbing grey medium (camera inside, IOR 1, emitter 2 units ahead): a
+    sample either dies at a medium event (its connection has BSDF ds * phase = 0) or reaches the emitter as vertex 1,
+    which is scored with throughput 1 - the segment's decay is applied after the vertex is scored (:70-74) and
+    originProb is never divided out - so every surviving sample is exactly L and the pixel estimates
+    L * P(no event before d) = L exp(-sigma d): the path tracer's answer, by another route."""
+    cam = ra.make_camera(32, 32, 400, position=(0, 0, 1), focus=(0, 0, -1))
+    s = meshgen.fog_box_scene((0, 0, 0), (0.5, 0.5, 0.5))
+    S = orc.OracleScene(s.raw())
+    spp = 256
+    img, nr, ns = S.render_pttest(cam, spp, seed=2, threads=8)
+    block = (img / spp)[8:24, 8:24]
+    assert abs(block.mean() - 50 * np.exp(-1.0)) / (50 * np.exp(-1.0)) < 0.03, block.mean()
+    one, _, _ = S.render_pttest(cam, 1, seed=2, threads=8)
+    vals = np.unique(np.round(one[8:24, 8:24], 3))
+    assert set(vals.tolist()) <= {0.0, 50.0}, vals  # a sample is all or nothing
+    assert ns > 0  # the terminated medium vertices are RANDOM (SceneVPMObject.cpp:132): each one attempts a connection
+    S.close()
+    s.close()
+
+
 def test_pttest_converges_to_path_tracer(cornell_oracle, cornell):
     """PathTracerTest is the reference's cross-check of PathTracer: same expectation, less noise.
     64x64 view of the Cornell scene; block means compared."""
