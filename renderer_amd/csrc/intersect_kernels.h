@@ -768,15 +768,26 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
                 if (COUNT) boxes++;
                 // most boxes of a chain are left through a face well clear of the box's edges: proven in ~25
                 // instructions; the rest (and every flat box) takes the full classifier, then the reference test
-                if (!slab_exit_face_proven(N.lo, N.hi, c, pre)) {
-                    float lb;
-                    const int code = slab_classify(N.lo, N.hi, __float_as_int(N.hi.w) != 0, o, pre, lb);
-                    if (code != BOX_HIT && !(code == BOX_AMBIGUOUS && box_test(N.lo, N.hi, o, d).hit)) {
-                        redo = true;
-                        break;
+                int axis;
+                if (slab_exit_face_proven(N.lo, N.hi, c, pre, axis)) {
+                    if (COUNT && !box_test(N.lo, N.hi, o, d).hit)
+                        atomicAdd(&counters[3], 1ull);  // audit: a proven exit face the reference test does not share (must be 0)
+                    // the reference accepts this box through that face, hence every ancestor that shares the face's
+                    // plane bit for bit and is no narrower on the other two axes (NodeRec::jump): go on above them
+                    const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+                    const int face = 2 * axis + (da > 0.f ? 1 : 0);
+                    if (COUNT) {  // audit: every ancestor skipped must pass the reference test as well (must be 0)
+                        for (int a2 = __float_as_int(N.lo.w); a2 >= 0 && a2 != N.jump[face]; a2 = __float_as_int(sc.rnodes[a2].lo.w))
+                            if (!box_test(sc.rnodes[a2].lo, sc.rnodes[a2].hi, o, d).hit) atomicAdd(&counters[3], 1ull);
                     }
-                } else if (COUNT && !box_test(N.lo, N.hi, o, d).hit) {
-                    atomicAdd(&counters[3], 1ull);  // audit: a proven exit face the reference test does not share (must be 0)
+                    node = N.jump[face];
+                    continue;
+                }
+                float lb;
+                const int code = slab_classify(N.lo, N.hi, __float_as_int(N.hi.w) != 0, o, pre, lb);
+                if (code != BOX_HIT && !(code == BOX_AMBIGUOUS && box_test(N.lo, N.hi, o, d).hit)) {
+                    redo = true;
+                    break;
                 }
                 node = __float_as_int(N.lo.w);
             }

@@ -842,7 +842,29 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
             memcpy(&ff, &flat, 4);
             rnodes[i].lo = make_float4(mn[0], mn[1], mn[2], fp);
             rnodes[i].hi = make_float4(mx[0], mx[1], mx[2], ff);
+            rnodes[i].pad[0] = rnodes[i].pad[1] = 0;
         }
+        // NodeRec::jump (mirt_dev.h). Pre-order puts a parent before its children, so the parent's entries are final
+        // when a child asks: the child's chain for a face runs on through the parent's exactly when the parent
+        // inherits the face (same plane bits, other two axes no narrower; both CHECKED on the caller's boxes), and
+        // inheriting is transitive along such a run (same plane again, containment of containment).
+        for (int i = 0; i < N; i++)
+            for (int f = 0; f < 6; f++) {
+                const int p = parent[i];
+                int j = p;
+                if (p >= 0) {
+                    const int a = f >> 1, b1 = (a + 1) % 3, b2 = (a + 2) % 3;
+                    const float* cn = s->node_min + 3 * i;
+                    const float* cx = s->node_max + 3 * i;
+                    const float* pn = s->node_min + 3 * p;
+                    const float* px = s->node_max + 3 * p;
+                    const float cplane = (f & 1) ? cx[a] : cn[a], pplane = (f & 1) ? px[a] : pn[a];
+                    const bool same = memcmp(&cplane, &pplane, 4) == 0;
+                    const bool contains = pn[b1] <= cn[b1] && px[b1] >= cx[b1] && pn[b2] <= cn[b2] && px[b2] >= cx[b2];
+                    if (same && contains) j = rnodes[p].jump[f];
+                }
+                rnodes[i].jump[f] = j;
+            }
         if (use_fast) {
             FastTree ft;
             const float bmax = std::max(bound[0], std::max(bound[1], bound[2]));

@@ -16,10 +16,20 @@
 namespace mirt {
 
 // ---- HBM layout ------------------------------------------------------------------------------
-// reference-tree node record, 32 B, pre-order: what k_verify walks from a leaf up to the root
+// reference-tree node record, 64 B, pre-order: what k_verify walks from a leaf up to the root
 //   lo = (min.x, min.y, min.z, bits(parent index, -1 for the root))   hi = (max.x, max.y, max.z, bits(flat))
+//   jump[face], face = 2 * axis + (1 for the max plane): the nearest ancestor that does NOT inherit this node's
+//   acceptance through that face, -1 when every ancestor up to the root does. An ancestor inherits it when its plane on
+//   that face is this node's plane bit for bit and its bounds on the other two axes contain this node's: the reference
+//   test (KDTree.cpp:40-49) then computes the very same t = (plane - o) / d and the very same point o + t d for that
+//   face, and a point inside the node's other two slabs (inclusive compares) is inside the wider ones. So "the
+//   reference accepts this node through face F" implies, exactly and with no margin, that it accepts every ancestor
+//   below jump[F]: k_verify continues there instead of at the parent (built on the host from the caller's boxes with
+//   both conditions checked, never assumed).
 struct NodeRec {
     float4 lo, hi;
+    int jump[6];
+    int pad[2];
 };
 // traversal record, 64 B: the two children of one inner node, in BREADTH-FIRST order of the inner
 // nodes (the top of the tree is contiguous). Per child two float4, with each axis' two planes side
@@ -430,7 +440,9 @@ __device__ __forceinline__ bool slab_miss_pair(const float4 a, const float4 b, c
 // other two slabs on their entry side) and the exit is clear of the other two axes' exits (f2 - tf > M: inside them
 // on their exit side). The rounding of these t~ is within 3/16 of a_ray each, so differences of two of them and the
 // reference's own compare error still fit M. A box that fails this (flat boxes always do) goes to slab_classify.
-__device__ __forceinline__ bool slab_exit_face_proven(const float4 lo, const float4 hi, f3 c, const RayPre& p) {
+// `axis`: which axis' exit plane that face is (the unique smallest exit value when the proof holds: f2 - tf > M > 0);
+// the face itself is that axis' max plane for a positive direction component, its min plane otherwise.
+__device__ __forceinline__ bool slab_exit_face_proven(const float4 lo, const float4 hi, f3 c, const RayPre& p, int& axis) {
     const float t0x = __builtin_fmaf(lo.x, p.inv.x, c.x), t1x = __builtin_fmaf(hi.x, p.inv.x, c.x);
     const float t0y = __builtin_fmaf(lo.y, p.inv.y, c.y), t1y = __builtin_fmaf(hi.y, p.inv.y, c.y);
     const float t0z = __builtin_fmaf(lo.z, p.inv.z, c.z), t1z = __builtin_fmaf(hi.z, p.inv.z, c.z);
@@ -438,6 +450,7 @@ __device__ __forceinline__ bool slab_exit_face_proven(const float4 lo, const flo
     const float tn = fmaxf(fminf(t0x, t1x), fmaxf(fminf(t0y, t1y), fminf(t0z, t1z)));
     const float tf = fminf(fx, fminf(fy, fz)), f2 = __builtin_amdgcn_fmed3f(fx, fy, fz);
     const float M = __builtin_fmaf(1.9073486e-06f /*32 * 2^-24*/, fabsf(tn) + fabsf(tf), p.a_ray);
+    axis = fx == tf ? 0 : (fy == tf ? 1 : 2);
     return (tf > M) & (tf - tn > M) & (f2 - tf > M);
 }
 __device__ __forceinline__ bool box_is_flat(const float4 lo, const float4 hi) {
