@@ -39,6 +39,7 @@ struct MirtContext {
     bool has_media = false;    // scene holds a homogeneous medium (MIRT_OBJ_VPM)
     bool media_ready = true;   // ... and every such object came with its own tree
     VolRoot* d_vols = nullptr;
+    VolNode* d_vnodes = nullptr;
     PairRec* d_fpairs = nullptr;    // fast tree (build_fast_tree) + what k_verify needs
     NodeRec* d_rnodes = nullptr;
     int* d_slot_node = nullptr;
@@ -219,7 +220,9 @@ static void free_scene(MirtContext* ctx) {
     hipFree(ctx->d_spill);
     ctx->d_spill = nullptr;
     hipFree(ctx->d_vols);
+    hipFree(ctx->d_vnodes);
     ctx->d_vols = nullptr;
+    ctx->d_vnodes = nullptr;
     hipFree(ctx->d_fpairs);
     hipFree(ctx->d_rnodes);
     hipFree(ctx->d_slot_node);
@@ -790,17 +793,32 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     float4 root_lo, root_hi;
     append_pairs(main_tree, 0, pairs, &root_lo, &root_hi, &depth);
     if (pairs.empty()) pairs.push_back(PairRec{});
-    // object trees share the pair / triangle arrays; their slots follow the scene's
+    // object trees (volumetric objects, for findInsideObject): pre-order nodes with escape indices (VolNode); their
+    // triangles take the slots behind the scene's, in the object tree's own leaf order
     std::vector<VolRoot> vols(n_obj_trees);
+    std::vector<VolNode> vnodes;
     {
         int slot_base = T;
         for (int k = 0; k < n_obj_trees; k++) {
-            // an object's boxes lie inside the scene's root box (same vertices), so `bound` covers them
-            if (!bounds_in_model(obj_view[k])) fast_ok = 0;
-            append_pairs(obj_view[k], slot_base, pairs, &vols[k].lo, &vols[k].hi, &obj_depth[k]);
+            const TreeView& v = obj_view[k];
             vols[k].object = obj_trees[k].object;
-            vols[k].pad[0] = vols[k].pad[1] = vols[k].pad[2] = 0;
-            depth = std::max(depth, obj_depth[k]);
+            vols[k].first = (int)vnodes.size();
+            vols[k].count = v.N;
+            vols[k].pad = 0;
+            std::vector<int> after(v.N);  // the node that follows node i's subtree in pre-order (right[i] > i)
+            for (int i = v.N - 1; i >= 0; i--) after[i] = v.right[i] < 0 ? i + 1 : after[v.right[i]];
+            for (int i = 0; i < v.N; i++) {
+                VolNode nd;
+                const int esc = vols[k].first + after[i];
+                float fe;
+                memcpy(&fe, &esc, 4);
+                nd.lo = make_float4(v.mn[3 * i], v.mn[3 * i + 1], v.mn[3 * i + 2], fe);
+                nd.hi = make_float4(v.mx[3 * i], v.mx[3 * i + 1], v.mx[3 * i + 2], 0.f);
+                nd.leaf_begin = v.right[i] < 0 ? slot_base + v.lbeg[i] : -1;
+                nd.leaf_end = v.right[i] < 0 ? slot_base + v.lend[i] : -1;
+                nd.pad[0] = nd.pad[1] = 0;
+                vnodes.push_back(nd);
+            }
             slot_base += s->objects[obj_trees[k].object].tri_count;
         }
     }
@@ -928,10 +946,9 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
         size_t slot = (size_t)T;
         for (int k = 0; k < n_obj_trees; k++) {
             const MirtObject& ob = s->objects[obj_trees[k].object];
-            const std::vector<int> src = seam_order(obj_view[k]);
-            for (int q = 0; q < ob.tri_count; q++) {
-                if (tri_vt) fill_vt(slot, ob.tri_begin + obj_trees[k].slot_tid[src[q]]);
-                fill_slot(slot++, ob.tri_begin + obj_trees[k].slot_tid[src[q]]);
+            for (int q = 0; q < ob.tri_count; q++) {  // (leaf ranges are kept whole: no seam order here)
+                if (tri_vt) fill_vt(slot, ob.tri_begin + obj_trees[k].slot_tid[q]);
+                fill_slot(slot++, ob.tri_begin + obj_trees[k].slot_tid[q]);
             }
         }
     }
@@ -1017,6 +1034,8 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     if (n_obj_trees > 0) {
         HIPCHK(ctx, hipMalloc(&ctx->d_vols, sizeof(VolRoot) * vols.size()));
         HIPCHK(ctx, hipMemcpy(ctx->d_vols, vols.data(), sizeof(VolRoot) * vols.size(), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMalloc(&ctx->d_vnodes, sizeof(VolNode) * vnodes.size()));
+        HIPCHK(ctx, hipMemcpy(ctx->d_vnodes, vnodes.data(), sizeof(VolNode) * vnodes.size(), hipMemcpyHostToDevice));
     }
     HIPCHK(ctx, hipMalloc(&ctx->d_fpairs, sizeof(PairRec) * fpairs.size()));
     HIPCHK(ctx, hipMemcpy(ctx->d_fpairs, fpairs.data(), sizeof(PairRec) * fpairs.size(), hipMemcpyHostToDevice));
@@ -1040,6 +1059,7 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     ctx->fast_all_modes = true;
     if (const char* e = getenv("MIRT_FAST_ALL_MODES")) ctx->fast_all_modes = atoi(e) != 0;  // A/B switch
     ctx->sc.vols = ctx->d_vols;
+    ctx->sc.vnodes = ctx->d_vnodes;
     ctx->sc.n_vols = n_obj_trees;
     if (!lights.empty()) {
         HIPCHK(ctx, hipMalloc(&ctx->d_lights, sizeof(DevLight) * lights.size()));

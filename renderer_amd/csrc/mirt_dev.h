@@ -113,11 +113,18 @@ struct DevLight {
     int first, count, object;
     int pad[2];
 };
-// root record of one volumetric object's own tree (Scene::objKDTrees, Scene.cpp:287-320):
-// lo.w = bits(link), hi.w = bits(flat), like a PairRec child
-struct VolRoot {
+// One volumetric object's own tree (Scene::objKDTrees, Scene.cpp:287-320) for Scene::findInsideObject: its nodes in
+// PRE-ORDER with an escape index, walked without a stack (pt_kernels.h trace_object): these trees are small (a fog
+// cube has 12 triangles) and are queried from inside the shade kernel, where a per-lane stack meant 528 B of scratch
+// memory per lane for every path of a scene that holds a medium.
+//   lo = (min.xyz, bits(escape)): the node that follows this node's whole subtree (VolRoot::first + count at the end)
+//   hi = (max.xyz, 0); leaf_begin / leaf_end: the leaf's triangle SLOTS (behind the scene's own), -1 for an inner node
+struct VolNode {
     float4 lo, hi;
-    int object, pad[3];
+    int leaf_begin, leaf_end, pad[2];
+};
+struct VolRoot {
+    int object, first, count, pad;  // nodes [first, first + count) of DevScene.vnodes
 };
 
 struct DevScene {
@@ -127,6 +134,7 @@ struct DevScene {
     const VnRec* vns;
     const DevObject* objects;
     const VolRoot* vols;  // per-object trees of the volumetric objects, ascending object index
+    const VolNode* vnodes;
     int n_vols;
     int n_nodes, n_tris, n_objects, depth;
     float bound[3];       // max |coordinate| of the root box per axis

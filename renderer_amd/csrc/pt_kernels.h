@@ -213,55 +213,31 @@ __device__ __forceinline__ float vignette_div(const DevCamera& c, uint32_t pixel
 }
 
 // ---- volumetric objects: Scene::findInsideObject (Scene.cpp:354-390) on the device ---------------
-// Unconditional closest hit inside ONE object's own tree (Scene::objKDTrees[i].intersect). Rare
-// (camera rays and boundary crossings of scenes that hold a medium), so: the reference box test
-// throughout, a private stack, nearer child first with the same pruning / tie rules as k_intersect.
+// Unconditional closest hit inside ONE object's own tree (Scene::objKDTrees[i].intersect): the reference box test
+// (KDTree.cpp:34-52) on every node whose parent passed, in pre-order with escape indices instead of a stack. The
+// reference visits both children of every node it enters and keeps the smallest t (later leaf on a tie, earlier
+// triangle inside a leaf: KDTree.cpp:305, 319-320); the order of the visit is free, and a subtree whose box starts
+// beyond the closest hit so far cannot change the answer (same pruning rule as k_intersect).
 __device__ inline float trace_object(const DevScene& sc, const VolRoot& R, f3 o, f3 d, int& slot_out) {
-    uint2 stk[MIRT_MAX_TREE_DEPTH + 2];
-    int sp = 0, best_slot = -1;
+    int best_slot = -1;
     float best = -1.f, thr = __builtin_inff();
-    int link = __float_as_int(R.lo.w);
-    bool has = box_test(R.lo, R.hi, o, d).hit;
-    auto pop = [&]() {
-        has = false;
-        while (sp > 0) {
-            sp--;
-            const uint2 e = stk[sp];
-            if (__uint_as_float(e.y) > thr) continue;
-            link = (int)e.x;
-            has = true;
-            break;
+    const int end = R.first + R.count;
+    for (int i = R.first; i < end;) {
+        const VolNode N = sc.vnodes[i];
+        const BoxHit b = box_test(N.lo, N.hi, o, d);
+        if (!b.hit || b.lb > thr) {
+            i = __float_as_int(N.lo.w);  // past the subtree
+            continue;
         }
-    };
-    while (has) {
-        if (link >= 0) {
-            const PairRec P = sc.pairs[link];
-            const BoxHit bl = box_test(pair_lo(P.la, P.lb), pair_hi(P.la, P.lb), o, d),
-                         br = box_test(pair_lo(P.ra, P.rb), pair_hi(P.ra, P.rb), o, d);
-            const bool vl = bl.hit && !(bl.lb > thr), vr = br.hit && !(br.lb > thr);
-            const int kl = __float_as_int(P.lb.z), kr = __float_as_int(P.rb.z);
-            const bool pick_l = vl && (!vr || bl.lb <= br.lb);
-            if (vl && vr) {
-                stk[sp] = make_uint2((uint32_t)(pick_l ? kr : kl), __float_as_uint(pick_l ? br.lb : bl.lb));
-                sp++;
-            }
-            if (vl || vr)
-                link = pick_l ? kl : kr;
-            else
-                pop();
-        } else {
-            const uint32_t v = ~(uint32_t)link;
-            const int beg = (int)(v & 0xFFFFFFu), end = beg + (int)(v >> 24);
-            for (int s = beg; s < end; s++) {
-                const float t = tri_test(sc.tris[s], o, d);
-                if (!(t >= 0.f)) continue;
-                if (!(best_slot < 0 || t < best || (t == best && best_slot < beg))) continue;
-                best = t;
-                best_slot = s;
-                thr = t * 1.0001f + 1e-5f;
-            }
-            pop();
+        for (int s = N.leaf_begin; s < N.leaf_end; s++) {
+            const float t = tri_test(sc.tris[s], o, d);
+            if (!(t >= 0.f)) continue;
+            if (!(best_slot < 0 || t < best || (t == best && best_slot < N.leaf_begin))) continue;
+            best = t;
+            best_slot = s;
+            thr = t * 1.0001f + 1e-5f;
         }
+        i++;  // first child, or (a leaf) the next node in pre-order
     }
     slot_out = best_slot;
     return best_slot >= 0 ? best : -1.f;
@@ -593,8 +569,7 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
 // per block). Results do not depend on the order of `out` (RNG and radiance slots are keyed by pid).
 // VOL: the scene holds a homogeneous medium (SceneVPMObject.cpp:4-233): the scatter of a path that
 // is inside one is the medium's (MCRenderer.cpp:167-170), camera rays look up their inside object
-// (Camera.cpp:35), and the private stack of trace_object costs scratch memory; scenes without media
-// run the VOL = false instantiation, which has none of it.
+// (Camera.cpp:35); scenes without media run the VOL = false instantiation, which has none of it.
 // NEE: PathTracerTest (PathTracerTest.cpp:20-78) instead of PathTracer: the throughput is the
 // reference's `throughput` there (no originProb, no camera cosine, no vignetting compensation), an
 // emitter hit is weighted against the light connection that could have found it, and every RANDOM
