@@ -218,8 +218,9 @@ uint64_t mirt_scene_serial(const MirtContext* ctx);
  * t_out: float[n]; tid_out: int32[n] global triangle id or -1. Host pointers.                */
 int mirt_intersect(MirtContext* ctx, const float* origins, const float* directions,
                    const int32_t* aux, size_t n, int mode, float* t_out, int32_t* tid_out);
-/* Same with DEVICE pointers; asynchronous on `stream` (a hipStream_t, NULL = context stream). One first-use
- * exception synchronises the stream once: a batch larger than any before (a list buffer grows). Every mode takes
+/* Same with DEVICE pointers; asynchronous on `stream` (a hipStream_t, NULL = context stream). It never synchronises; a
+ * batch larger than any before allocates a larger list buffer (hipMalloc; the outgrown one is kept until the next
+ * upload, so launches still in flight are unaffected). Every mode takes
  * the same route on a scene (the fast tree when the scene has one; MIRT_FAST_ALL_MODES=0 in the environment sends
  * modes 0 / 1 over the reference tree instead, for A/B runs; the answers are the same either way).            */
 int mirt_intersect_dev(MirtContext* ctx, const float* origins, const float* directions,

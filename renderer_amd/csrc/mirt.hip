@@ -48,6 +48,8 @@ struct MirtContext {
     int* d_vis_slot = nullptr;      // visibility through the fast tree: occluder slot per ray, for k_verify
     size_t vis_slot_cap = 0;
     size_t fb_cap = 0;
+    std::vector<void*> retired;     // list buffers outgrown by a larger batch: freed at the next upload / destroy, so that
+                                    // growing never has to wait for the launches that may still read the old one
     DevLight* d_lights = nullptr;   // emission sampler tables (PathTracerTest)
     VtRec* d_vts = nullptr;          // textures: corner texture coordinates per slot, texture records, texel pool
     DevTexture* d_textures = nullptr;
@@ -211,6 +213,11 @@ int mirt_create(int device, MirtContext** out) {
     return MIRT_OK;
 }
 
+static void free_retired(MirtContext* ctx) {  // (ensure_fb_list: buffers outgrown while launches might still read them)
+    for (void* p : ctx->retired) hipFree(p);
+    ctx->retired.clear();
+}
+
 static void free_scene(MirtContext* ctx) {
     hipFree(ctx->d_pairs);
     ctx->d_pairs = nullptr;
@@ -288,7 +295,7 @@ static void free_staging(MirtContext* ctx) {
 int mirt_destroy(MirtContext* ctx) {
     if (!ctx) return MIRT_OK;
     hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    hipDeviceSynchronize();  // (launches on the callers' own streams included)
     free_scene(ctx);
     free_paths(ctx);
     free_staging(ctx);
@@ -303,6 +310,7 @@ int mirt_destroy(MirtContext* ctx) {
     hipFree(ctx->d_queue);
     hipFree(ctx->d_fb_list);
     hipFree(ctx->d_vis_slot);
+    free_retired(ctx);
     if (ctx->h_cnt) hipHostFree(ctx->h_cnt);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1022,8 +1030,9 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     }
 
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipDeviceSynchronize());  // (callers' streams included: the scene they read is replaced below)
     free_scene(ctx);
+    free_retired(ctx);
     HIPCHK(ctx, hipMalloc(&ctx->d_pairs, sizeof(PairRec) * pairs.size()));
     HIPCHK(ctx, hipMemcpy(ctx->d_pairs, pairs.data(), sizeof(PairRec) * pairs.size(), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMalloc(&ctx->d_tris, sizeof(TriRec) * TT));
@@ -1230,16 +1239,18 @@ static int launch_mode(MirtContext* ctx, const LaunchBufs& lb, hipStream_t st, d
     return MIRT_OK;
 }
 
-// list buffer of the fast path: one entry per ray of the largest batch so far
+// list buffer of the fast path: one entry per ray of the largest batch so far. A larger batch than any before gets
+// a new buffer; the old one is parked (launches already enqueued on any stream may still use it) and freed at the
+// next upload / at destroy, so the call neither synchronises nor stalls the caller's pipeline.
 static int ensure_fb_list(MirtContext* ctx, hipStream_t st, uint32_t n) {
-    if (n <= ctx->fb_cap) return MIRT_OK;  // (first use / a larger batch than any before: not on the timed path)
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->d_fb_list);
+    (void)st;
+    if (n <= ctx->fb_cap) return MIRT_OK;
+    if (ctx->d_fb_list) ctx->retired.push_back(ctx->d_fb_list);
     ctx->d_fb_list = nullptr;
     ctx->fb_cap = 0;
-    HIPCHK(ctx, hipMalloc(&ctx->d_fb_list, (size_t)n * sizeof(uint32_t)));
-    ctx->fb_cap = n;
+    const size_t want = std::max<size_t>(n, 1u << 20);  // (small batches first: do not grow in many small steps)
+    HIPCHK(ctx, hipMalloc(&ctx->d_fb_list, want * sizeof(uint32_t)));
+    ctx->fb_cap = want;
     return MIRT_OK;
 }
 
@@ -1355,14 +1366,13 @@ static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const f
     if (mode == MIRT_MODE_NO_SELF && ctx->fast_tree && vis_fast) {
         int rc = ensure_fb_list(ctx, st, n);
         if (rc != MIRT_OK) return rc;
-        if (n > ctx->vis_slot_cap) {
-            HIPCHK(ctx, hipStreamSynchronize(st));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            hipFree(ctx->d_vis_slot);
+        if (n > ctx->vis_slot_cap) {  // (as ensure_fb_list: the outgrown buffer is parked, nothing waits)
+            if (ctx->d_vis_slot) ctx->retired.push_back(ctx->d_vis_slot);
             ctx->d_vis_slot = nullptr;
             ctx->vis_slot_cap = 0;
-            HIPCHK(ctx, hipMalloc(&ctx->d_vis_slot, (size_t)n * sizeof(int)));
-            ctx->vis_slot_cap = n;
+            const size_t want = std::max<size_t>(n, 1u << 20);
+            HIPCHK(ctx, hipMalloc(&ctx->d_vis_slot, want * sizeof(int)));
+            ctx->vis_slot_cap = want;
         }
         const dim3 gfast(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks_fast));
         hipLaunchKernelGGL((k_intersect<MIRT_MODE_NO_SELF, false, false, true, true>), gfast, block, ctx->lds_main_fast, st,

@@ -63,3 +63,45 @@ def test_noalloc_limits(gpu, cornell, ra):
     (t_ref, i_ref), (t_na, i_na) = _pair(gpu, ra, torch, o, d, a, ra.MODE_NO_SELF)
     assert np.array_equal(i_na, i_ref) and np.array_equal(t_na, t_ref)
     gpu.intersect_noalloc_dev(buf.data_ptr(), buf.data_ptr(), None, 0, ra.MODE_UNCONDITIONAL, t.data_ptr(), i.data_ptr())
+
+
+def test_noalloc_allocates_nothing_and_caps_the_grid(cornell, ra):
+    """The entry point's contract itself: on a FRESH context the first closest-hit call ever is the
+    no-alloc one with the largest batch it takes, and the device's free memory must not move (mirt_intersect_dev would
+    hipMalloc its list buffer at that point). Then the same with MIRT_LDS_LEVELS=1 at upload, which leaves almost every
+    stack level in the static spill slice so that the persistent grid has to be cut down to fit its 32 MiB."""
+    import os
+    import torch
+
+    o, d, a = meshgen.random_rays(ra.NOALLOC_MAX_RAYS, 94, cornell.n_objects, inside_obj=2)
+    d[1, :30000] = 0.0  # rays for the re-run list
+    d[:, :30000] /= np.maximum(np.linalg.norm(d[:, :30000], axis=0, keepdims=True), 1e-30)
+    n = o.shape[1]
+    to, td, ta = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), torch.from_numpy(a).cuda()
+    t = torch.empty(n, dtype=torch.float32, device="cuda")
+    i = torch.empty(n, dtype=torch.int32, device="cuda")
+    ref_dev = ra.Device(device=0)
+    ref_dev.upload(cornell.describe())
+    t_ref = torch.empty_like(t)
+    i_ref = torch.empty_like(i)
+    ref_dev.intersect_dev(to.data_ptr(), td.data_ptr(), ta.data_ptr(), n, ra.MODE_NO_SELF, t_ref.data_ptr(), i_ref.data_ptr())
+    torch.cuda.synchronize()
+    for levels in (None, "1"):
+        if levels:
+            os.environ["MIRT_LDS_LEVELS"] = levels
+        try:
+            dev = ra.Device(device=0)
+            dev.upload(cornell.describe())
+        finally:
+            os.environ.pop("MIRT_LDS_LEVELS", None)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        for mode, aux in ((ra.MODE_NO_SELF, ta.data_ptr()), (ra.MODE_UNCONDITIONAL, None)):
+            dev.intersect_noalloc_dev(to.data_ptr(), td.data_ptr(), aux, n, mode, t.data_ptr(), i.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free0, "mirt_intersect_noalloc_dev changed the device's free memory"
+        dev.intersect_noalloc_dev(to.data_ptr(), td.data_ptr(), ta.data_ptr(), n, ra.MODE_NO_SELF, t.data_ptr(), i.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(i, i_ref) and torch.equal(t, t_ref), levels
+        dev.close()
+    ref_dev.close()
