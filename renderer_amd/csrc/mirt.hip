@@ -1793,17 +1793,21 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_L, 0, 3 * ctx->pb_cap * sizeof(float), st));  // (generation 0 of the L ring)
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt, 0, words * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_ab, 0, 64 * words * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_wq, 0, 3 * words * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_generate, dim3((P + B - 1) / B), dim3(B), 0, st, cam, P, s0, prm->seed, cur->o,
                        cur->d, cur->stride, *cur, nee ? 2 : 1);
     HIPCHK(ctx, hipGetLastError());
-    auto timed_intersect = [&](int mode, PathBuf* pb, uint32_t n, const uint32_t* n_ptr, uint32_t* queue) -> int {
+    auto timed_intersect = [&](int mode, PathBuf* pb, uint32_t n, const uint32_t* n_ptr, uint32_t* queue,
+                               const uint32_t* off = nullptr) -> int {
         hipEvent_t e0 = get_event(ctx, *ev_used), e1 = get_event(ctx, *ev_used + 1);
         if (!e0 || !e1) return fail(ctx, MIRT_E_HIP, "hipEventCreate failed");
         *ev_used += 2;
         HIPCHK(ctx, hipEventRecord(e0, st));
+        ctx->cur_off = off;  // (where the batch starts in pb's arrays: two-ended compaction)
         int rc = launch_intersect<false, true>(ctx, st, mode, pb->o, pb->d, pb->ids, n, pb->stride,
                                                pb->t, pb->slot, n_ptr, queue);
+        ctx->cur_off = nullptr;
         if (rc != MIRT_OK) return rc;
         HIPCHK(ctx, hipEventRecord(e1, st));
         return MIRT_OK;
@@ -1815,19 +1819,25 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
     uint32_t depths_run = 0;
     for (uint32_t depth = 0; depth <= prm->max_depth; depth++) {
         const uint32_t* n_in = depth ? ctx->d_cnt + depth : nullptr;
+        const uint32_t* off_in = depth ? ctx->d_off + depth : nullptr;  // (camera hits lie at [0, P))
         uint32_t* n_out = ctx->d_cnt + depth + 1;
+        uint32_t* off_out = ctx->d_off + depth + 1;
+        uint32_t* ab = ctx->d_ab + 64 * (size_t)(depth + 1);
+        // two-ended compaction (pt_kernels.h, k_shade<.., TWO>): survivors land in [mid - ab[32], mid + ab[0]); k_live
+        // turns the two counters into the range's length (n_out) and start (off_out) for the next launches
+        const uint32_t sgrid = (bound + SHADE_BLOCK - 1) / SHADE_BLOCK, mid = (sgrid >> 1) * (uint32_t)SHADE_BLOCK;
         if (nee) {
             // PathTracerTest: shade writes one shadow ray per RANDOM vertex; the visibility launch and
             // k_connect add the unoccluded contributions before the next bounce touches L again
             uint32_t* n_sh = ctx->d_ns + depth;
             if (ctx->has_media)
-                hipLaunchKernelGGL((k_shade<true, true>), dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur,
-                                   n_in, bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth,
-                                   ctx->shb, n_sh);
+                hipLaunchKernelGGL((k_shade<true, true, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur,
+                                   n_in, bound, *nxt, ab, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth,
+                                   ctx->shb, n_sh, off_in);
             else
-                hipLaunchKernelGGL((k_shade<false, true>), dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur,
-                                   n_in, bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth,
-                                   ctx->shb, n_sh);
+                hipLaunchKernelGGL((k_shade<false, true, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur,
+                                   n_in, bound, *nxt, ab, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth,
+                                   ctx->shb, n_sh, off_in);
             HIPCHK(ctx, hipGetLastError());
             int rcv = launch_visibility(ctx, st, MIRT_MODE_NO_SELF, ctx->shb.o, ctx->shb.d, ctx->shb.ids, ctx->shb.lim,
                                         bound, ctx->shb.stride, ctx->shb.vis, n_sh, ctx->d_wq2 + 3 * depth);
@@ -1835,37 +1845,45 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
             hipLaunchKernelGGL(k_connect, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->shb, n_sh, bound, ctx->d_L,
                                (uint32_t)ctx->pb_cap);
         } else if (ctx->has_media)
-            hipLaunchKernelGGL(k_shade<true>, dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in,
-                               bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth);
+            hipLaunchKernelGGL((k_shade<true, false, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in,
+                               bound, *nxt, ab, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth, ShadowBuf{},
+                               (uint32_t*)nullptr, off_in);
         else
-            hipLaunchKernelGGL(k_shade<false>, dim3((bound + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in,
-                               bound, *nxt, n_out, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth);
+            hipLaunchKernelGGL((k_shade<false, false, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in,
+                               bound, *nxt, ab, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth, ShadowBuf{},
+                               (uint32_t*)nullptr, off_in);
+        HIPCHK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_live, dim3(1), dim3(1), 0, st, (const uint32_t*)ab, mid, n_out, off_out);
         HIPCHK(ctx, hipGetLastError());
         depths_run = depth + 1;
         if (depth == prm->max_depth) break;  // nothing survives the depth cap (MCRenderer.cpp:187-191)
         std::swap(cur, nxt);
         // look at the count when capturing, and at depths 4, 8, 16, ... to stop early / shrink grids
         const bool look = cap || (depth >= 3 && ((depth + 1) & depth) == 0);
+        uint32_t off_host = 0;
         if (look) {
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, n_out, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt + 1, off_out, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
             const uint32_t n = ctx->h_cnt[0];
-            if (n > bound) return fail(ctx, MIRT_E_HIP, "wavefront: live-path counter corrupted");
+            off_host = ctx->h_cnt[1];
+            if (n > bound || (size_t)off_host + n > (size_t)cur->stride)
+                return fail(ctx, MIRT_E_HIP, "wavefront: live-path counter corrupted");
             bound = n;
             if (n == 0) break;
         }
         if (cap && depth + 1 >= cap->depth_lo && depth + 1 <= cap->depth_hi && cap->count < cap->capacity) {
             size_t m = std::min((size_t)bound, cap->capacity - cap->count);
             for (int c = 0; c < 3; c++) {
-                HIPCHK(ctx, hipMemcpyAsync(cap->o + c * cap->capacity + cap->count, cur->o + (size_t)c * cur->stride,
+                HIPCHK(ctx, hipMemcpyAsync(cap->o + c * cap->capacity + cap->count, cur->o + (size_t)c * cur->stride + off_host,
                                            m * sizeof(float), hipMemcpyDeviceToDevice, st));
-                HIPCHK(ctx, hipMemcpyAsync(cap->d + c * cap->capacity + cap->count, cur->d + (size_t)c * cur->stride,
+                HIPCHK(ctx, hipMemcpyAsync(cap->d + c * cap->capacity + cap->count, cur->d + (size_t)c * cur->stride + off_host,
                                            m * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
-            HIPCHK(ctx, hipMemcpyAsync(cap->aux + cap->count, cur->ids, m * sizeof(int), hipMemcpyDeviceToDevice, st));
+            HIPCHK(ctx, hipMemcpyAsync(cap->aux + cap->count, cur->ids + off_host, m * sizeof(int), hipMemcpyDeviceToDevice, st));
             cap->count += m;
         }
-        rc = timed_intersect(MIRT_MODE_NO_SELF, cur, bound, n_out, ctx->d_wq + 3 * (depth + 1));  // MCRenderer.cpp:193-197
+        rc = timed_intersect(MIRT_MODE_NO_SELF, cur, bound, n_out, ctx->d_wq + 3 * (depth + 1), off_out);  // MCRenderer.cpp:193-197
         if (rc != MIRT_OK) return rc;
     }
     if (rgb_sum) {
