@@ -24,6 +24,11 @@ int mirth_load_config(const char* config_path, MirthScene** out);
 int mirth_scene_from_arrays(int32_t n_verts, const float* verts, int32_t n_tris, const uint32_t* tris,
                             const int32_t* tri_obj, const float* tri_vn, int32_t n_objects,
                             const MirtObject* objects, MirthScene** out);
+/* KDTree::build(Strategy) (KDTree.cpp:230-246, KDTree.h:24) on the scene's tree: strategy 0 = LOOP (splitLoop, the split
+ * axis cycles x, y, z with the depth), 1 = BEST (splitBest, what loading builds and every reference caller uses).
+ * Any resident copy becomes stale (the next upload sends the new tree). The answers of the closest-hit query do not
+ * depend on the strategy except where two triangles tie (the traversal order decides those).                        */
+int mirth_rebuild_tree(MirthScene* s, int32_t strategy);
 /* Gives a scene made from arrays its textures (copied): corner texture coordinates [T*9] by global triangle
  * id (may be NULL), the textures, and which of them each object's materials read [n_objects]
  * (MirtTexture / MirtObjectTex, include/mirt.h). A scene loaded from a config has them from its XML.   */

@@ -211,6 +211,55 @@ void splitBest(OrcScene& S, Node* node, int depth, int& maxDepthSeen) {
     splitBest(S, node->right, depth + 1, maxDepthSeen);
 }
 
+// KDTree.cpp:54-127: the split axis is handed down ((dim+1)%3 per level) instead of chosen
+void splitLoop(OrcScene& S, Node* node, unsigned dim, int depth, int& maxDepthSeen) {
+    if (depth > maxDepthSeen) maxDepthSeen = depth;
+    node->left = node->right = nullptr;
+    if (node->triangleIndices.size() == 0) return;
+    node->minCoord = node->maxCoord = S.verts[S.tris[node->triangleIndices[0]].v[0]];
+    std::unordered_set<unsigned> nodeVertexIndices;
+    for (size_t i = 0; i < node->triangleIndices.size(); i++) {
+        for (unsigned k = 0; k < 3; k++) {
+            unsigned vi = S.tris[node->triangleIndices[i]].v[k];
+            const V3& p = S.verts[vi];
+            for (int c = 0; c < 3; c++) {
+                node->minCoord[c] = p[c] < node->minCoord[c] ? p[c] : node->minCoord[c];
+                node->maxCoord[c] = p[c] > node->maxCoord[c] ? p[c] : node->maxCoord[c];
+            }
+            nodeVertexIndices.insert(vi);
+        }
+    }
+    if (node->triangleIndices.size() <= 1) return;  // maxLeafTriangleNum = 1; maxDepth = (unsigned)-1 never binds
+    std::vector<float> coordList;
+    for (unsigned vi : nodeVertexIndices) coordList.push_back(S.verts[vi][dim]);
+    std::nth_element(coordList.begin(), coordList.begin() + (coordList.size() >> 1), coordList.end());
+    float splitValue = coordList[coordList.size() >> 1];
+    node->left = new Node;
+    node->right = new Node;
+    unsigned leftCount = 0;
+    for (size_t i = 0; i < node->triangleIndices.size(); i++) {
+        unsigned mask = 0;
+        for (unsigned k = 0; k < 3; k++) {
+            const V3& p = S.verts[S.tris[node->triangleIndices[i]].v[k]];
+            mask += (p[dim] <= splitValue) << k;
+        }
+        if (mask == 0)
+            node->right->triangleIndices.push_back(node->triangleIndices[i]);
+        else {
+            node->left->triangleIndices.push_back(node->triangleIndices[i]);
+            leftCount++;
+        }
+    }
+    if (leftCount == 0 || leftCount == node->triangleIndices.size()) {
+        delete node->left;
+        delete node->right;
+        node->left = node->right = nullptr;
+        return;
+    }
+    splitLoop(S, node->left, (dim + 1) % 3, depth + 1, maxDepthSeen);
+    splitLoop(S, node->right, (dim + 1) % 3, depth + 1, maxDepthSeen);
+}
+
 // KDTree.cpp:34-52
 float boxIntersect(const V3& minC, const V3& maxC, const KRay& ray) {
     V3 intPoint;
@@ -1805,6 +1854,21 @@ void orc_mat_apply(const float m[16], const float v[3], float w, float out[3]) {
 void orc_tex_coord(const OrcScene* s, int32_t tid, const float pos[3], float out[3]) {
     const V3 c = texCoord(*s, (unsigned)tid, V3(pos[0], pos[1], pos[2]));
     out[0] = c.x, out[1] = c.y, out[2] = c.z;
+}
+
+// KDTree::build(Strategy), KDTree.cpp:230-246, on the scene's main tree: 0 = LOOP, 1 = BEST (KDTree.h:24)
+void orc_scene_rebuild(OrcScene* S, int32_t strategy) {
+    destroyNode(S->root);
+    S->root = new Node;
+    for (size_t i = 0; i < S->tris.size(); i++) S->root->triangleIndices.push_back((unsigned)i);
+    int md = 0;
+    if (strategy == 0)
+        splitLoop(*S, S->root, 0, 0, md);
+    else
+        splitBest(*S, S->root, 0, md);
+    S->depth = md;
+    S->fmin.clear(), S->fmax.clear(), S->fright.clear(), S->fbegin.clear(), S->fend.clear(), S->slotTid.clear();
+    if (!S->tris.empty()) flattenNode(*S, S->root);
 }
 
 void orc_scene_destroy(OrcScene* s) {

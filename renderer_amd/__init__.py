@@ -100,7 +100,7 @@ MIRT_SYMBOLS = ["mirt_create", "mirt_destroy", "mirt_last_error", "mirt_upload_s
                 "mirt_render_pt_tile_dev", "mirt_render_pttest_tile_dev", "mirt_shard_tile", "mirt_render_pt_multi_shard",
                 "mirt_render_pttest_multi_shard", "mirt_context_device",
                 "mirt_capture_rays_dev", "mirt_device_info"]
-MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_set_textures", "mirth_free",
+MIRTH_SYMBOLS = ["mirth_last_error", "mirth_load_config", "mirth_scene_from_arrays", "mirth_rebuild_tree", "mirth_set_textures", "mirth_free",
                  "mirth_counts", "mirth_get_raw", "mirth_get_tree", "mirth_get_camera", "mirth_get_render_cfg",
                  "mirth_describe", "mirth_upload", "mirth_render", "mirth_render_progressive", "mirth_fill_intersect", "mirth_test_visibility", "mirth_test_path_list_visibility", "mirth_world_vertex", "mirth_normal_transform",
                  "mirth_shutdown", "mirth_is_resident", "mirth_set_devices",
@@ -177,6 +177,7 @@ def lib():
                                               C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
         L.mirth_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int32 * 5)]
         L.mirth_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.mirth_rebuild_tree.argtypes = [C.c_void_p, C.c_int32]
         L.mirth_get_raw.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.mirth_get_tree.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.mirth_get_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
@@ -213,6 +214,9 @@ class HostScene:
 
     def __init__(self, handle):
         self.h = handle
+        self._refresh_counts()
+
+    def _refresh_counts(self):
         cnt = (C.c_int32 * 5)()
         lib().mirth_counts(self.h, C.byref(cnt))
         self.n_verts, self.n_tris, self.n_objects, self.n_nodes, self.depth = list(cnt)
@@ -238,6 +242,14 @@ class HostScene:
         if rc != 0:
             raise MirtError(lib().mirth_last_error().decode())
         return HostScene(h)
+
+    LOOP, BEST = 0, 1  # KDTree::Strategy (KDTree.h:24)
+
+    def rebuild_tree(self, strategy):
+        """KDTree::build(strategy): LOOP cycles the split axis with the depth, BEST (the loader's) picks it per node."""
+        if lib().mirth_rebuild_tree(self.h, strategy) != 0:
+            raise MirtError(lib().mirth_last_error().decode())
+        self._refresh_counts()
 
     def set_textures(self, tri_vt, textures, object_tex):
         """tri_vt: (T, 9) corner texture coordinates or None; textures: list of make_texture() dicts;

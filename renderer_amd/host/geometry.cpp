@@ -83,8 +83,36 @@ void SimpleShape::loadShape(const std::string& fileName, bool normalize, std::ve
     vertexTexCoordList.clear();
     faceVertexNormalIndexList.clear();
     faceVertexTexCoordIndexList.clear();
-    if (fileName.size() < 4 || fileName.substr(fileName.size() - 4) != ".obj")
-        throw std::runtime_error("loadShape: only .obj meshes are supported: " + fileName);
+    const std::string suffix = fileName.size() >= 4 ? fileName.substr(fileName.size() - 4) : std::string();
+    if (suffix == ".shp") {
+        // SimpleShape.cpp:52-64, the binary dump SimpleShape::saveShape writes (:341-357): an int count of FLOATS and
+        // the vertex coordinates, an int count of INDICES and the face indices. The reference resizes both lists to
+        // those counts, i.e. to three times the number of vertices / faces, and reads into their heads: the tails stay
+        // zero - extra vertices at the origin and extra faces (0, 0, 0). Kept as it is (they are degenerate triangles
+        // on vertex 0 that the tree and the triangle test handle like any other).
+        FILE* f = fopen(fileName.c_str(), "rb");
+        if (!f) throw std::runtime_error("loadShape: cannot open " + fileName);
+        int size = 0;
+        bool ok = fread(&size, sizeof(int), 1, f) == 1 && size >= 0 && size < (1 << 28);
+        if (ok) {
+            vertexList.assign((size_t)size, vec3f(0, 0, 0));
+            ok = size == 0 || fread(reinterpret_cast<float*>(vertexList.data()), sizeof(float), (size_t)size, f) == (size_t)size;
+        }
+        if (ok) ok = fread(&size, sizeof(int), 1, f) == 1 && size >= 0 && size < (1 << 28);
+        if (ok) {
+            faceVertexIndexList.assign((size_t)size, vec3ui{0, 0, 0});
+            ok = size == 0 || fread(reinterpret_cast<unsigned*>(faceVertexIndexList.data()), sizeof(unsigned), (size_t)size, f) == (size_t)size;
+        }
+        fclose(f);
+        if (!ok) throw std::runtime_error("loadShape: truncated or malformed .shp file " + fileName);
+        for (const vec3ui& fi : faceVertexIndexList)
+            for (int k = 0; k < 3; k++)
+                if (fi[k] >= vertexList.size()) throw std::runtime_error("loadShape: face index out of range in " + fileName);
+        if (split) throw std::runtime_error("loadShape: a .shp file has no groups to split: " + fileName);
+        // the common tail below (SimpleShape.cpp:183-196: unitize when asked, bounding box) is shared with .obj
+    } else {
+    if (suffix != ".obj")
+        throw std::runtime_error("loadShape: only .obj and .shp meshes are supported: " + fileName);
     FILE* file = fopen(fileName.c_str(), "r");
     if (!file) throw std::runtime_error("loadShape: cannot open " + fileName);
     char line[1024], attrib[1024], parms[3][1024];
@@ -174,6 +202,7 @@ void SimpleShape::loadShape(const std::string& fileName, bool normalize, std::ve
                 dropSplit();
                 throw std::runtime_error("loadShape: normal index out of range in " + fileName);
             }
+    }  // .obj
     if (normalize) {
         const matrix4 unitizeMat = unitize();
         if (split)  // SimpleShape.cpp:186-194
@@ -233,9 +262,12 @@ vec3f KDTree::getDiagonal() const {
 // One node of the median-split tree (KDTree::splitBest, KDTree.cpp:129-228), emitted in pre-order.
 // `order[begin,end)` holds the node's triangles in the reference's order (a stable partition keeps
 // it), so a leaf's slot range is simply [begin,end).
+// loopDim >= 0: KDTree::splitLoop (KDTree.cpp:54-127) instead: the split axis is given (it cycles with the depth), no
+// choice among the axes; everything else (median of the distinct vertices' coordinates, "any vertex <= split goes
+// left", a split that separates nothing makes a leaf) is the same rule.
 void KDTree::buildNode(std::vector<unsigned>& order, size_t begin, size_t end, int level,
                        std::vector<unsigned>& stamp, unsigned& stampGen, std::vector<unsigned>& uniq,
-                       std::vector<float>& coords) {
+                       std::vector<float>& coords, int loopDim) {
     const size_t me = nodeRight.size();
     nodeRight.push_back(-1);
     nodeLeafBegin.push_back(-1);
@@ -277,6 +309,7 @@ void KDTree::buildNode(std::vector<unsigned>& order, size_t begin, size_t end, i
     int bestDim = 0;
     float bestSplit = 0;
     for (int dim = 0; dim < 3; dim++) {
+        if (loopDim >= 0 && dim != loopDim) continue;
         coords.resize(uniq.size());
         for (size_t i = 0; i < uniq.size(); i++) coords[i] = vertexPositionList[uniq[i]][dim];
         size_t mid = coords.size() >> 1;
@@ -290,7 +323,7 @@ void KDTree::buildNode(std::vector<unsigned>& order, size_t begin, size_t end, i
         }
         float ratio = (unsigned)left / float(count);
         // the reference compares in double: abs(ratio - 0.5) with a double literal (KDTree.cpp:191)
-        if (std::fabs((double)ratio - 0.5) < std::fabs((double)bestRatio - 0.5)) {
+        if (loopDim >= 0 || std::fabs((double)ratio - 0.5) < std::fabs((double)bestRatio - 0.5)) {
             bestRatio = ratio;
             bestDim = dim;
             bestSplit = split;
@@ -306,12 +339,13 @@ void KDTree::buildNode(std::vector<unsigned>& order, size_t begin, size_t end, i
                vertexPositionList[v.z][bestDim] <= bestSplit;
     };
     size_t mid = std::stable_partition(order.begin() + begin, order.begin() + end, goesLeft) - order.begin();
-    buildNode(order, begin, mid, level + 1, stamp, stampGen, uniq, coords);
+    const int nextDim = loopDim >= 0 ? (loopDim + 1) % 3 : -1;  // KDTree.cpp:125-126
+    buildNode(order, begin, mid, level + 1, stamp, stampGen, uniq, coords, nextDim);
     nodeRight[me] = (int32_t)nodeRight.size();
-    buildNode(order, mid, end, level + 1, stamp, stampGen, uniq, coords);
+    buildNode(order, mid, end, level + 1, stamp, stampGen, uniq, coords, nextDim);
 }
 
-void KDTree::build() {
+void KDTree::build(Strategy strategy) {
     nodeMin.clear();
     nodeMax.clear();
     nodeRight.clear();
@@ -329,7 +363,7 @@ void KDTree::build() {
     std::vector<unsigned> stamp(vertexPositionList.size(), 0), uniq;
     std::vector<float> coords;
     unsigned gen = 0;
-    buildNode(order, 0, order.size(), 0, stamp, gen, uniq, coords);
+    buildNode(order, 0, order.size(), 0, stamp, gen, uniq, coords, strategy == LOOP ? 0 : -1);  // KDTree.cpp:237-244
     slotTid.assign(order.begin(), order.end());
 }
 

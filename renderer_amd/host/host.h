@@ -138,7 +138,10 @@ public:
     std::vector<float> nodeMin, nodeMax;  // 3 per node
     std::vector<int32_t> nodeRight, nodeLeafBegin, nodeLeafEnd, slotTid;
     int depth = 0;
-    void build();
+    // KDTree.h:24: LOOP cycles the split axis x, y, z, x, ... with the depth (splitLoop, KDTree.cpp:54-127); BEST (the
+    // default, KDTree.h:54) takes per node the axis whose median split is most balanced (splitBest, KDTree.cpp:129-228)
+    enum Strategy { LOOP, BEST };
+    void build(Strategy strategy = BEST);
     void destroy();
     bool built() const { return !nodeRight.empty(); }
     vec3f getDiagonal() const;
@@ -147,7 +150,7 @@ public:
 private:
     void buildNode(std::vector<unsigned>& order, size_t begin, size_t end, int level,
                    std::vector<unsigned>& stamp, unsigned& stampGen, std::vector<unsigned>& uniq,
-                   std::vector<float>& coords);
+                   std::vector<float>& coords, int loopDim = -1);
 };
 
 // Camera.h:12-30

@@ -111,6 +111,21 @@ int mirth_scene_from_arrays(int32_t n_verts, const float* verts, int32_t n_tris,
     return 0;
 }
 
+int mirth_rebuild_tree(MirthScene* s, int32_t strategy) {
+    if (!s || (strategy != KDTree::LOOP && strategy != KDTree::BEST)) {
+        g_err = "mirth_rebuild_tree: NULL scene or unknown strategy (0 = LOOP, 1 = BEST)";
+        return -1;
+    }
+    try {
+        s->renderer.scene.tree.build((KDTree::Strategy)strategy);
+        s->renderer.scene.touch();  // a resident copy is stale now
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+    return 0;
+}
+
 int mirth_set_textures(MirthScene* s, const float* tri_vt, int32_t n_textures, const MirtTexture* textures,
                        const MirtObjectTex* object_tex) {
     if (!s || n_textures < 0 || (n_textures > 0 && (!textures || !object_tex))) {

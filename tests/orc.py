@@ -32,6 +32,8 @@ def lib():
         L.orc_scene_create.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int32, C.c_void_p]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_rebuild.argtypes = [C.c_void_p, C.c_int32]
+        L.orc_scene_rebuild.restype = None
         L.orc_scene_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.orc_scene_set_textures.restype = None
         L.orc_texture_color.argtypes = [C.c_void_p] * 3
@@ -111,6 +113,12 @@ class OracleScene:
         if self.h:
             lib().orc_scene_destroy(self.h)
             self.h = None
+
+    def rebuild(self, strategy):
+        """KDTree::build(strategy): 0 = LOOP, 1 = BEST"""
+        lib().orc_scene_rebuild(self.h, strategy)
+        self.n_nodes = lib().orc_tree_num_nodes(self.h)
+        self.depth = lib().orc_tree_depth(self.h)
 
     def flatten(self):
         N, T = self.n_nodes, len(self.tris)

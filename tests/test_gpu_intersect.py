@@ -67,6 +67,26 @@ def test_mesh20k(gpu, mesh20k, mesh20k_oracle, ra):
         _check(tg, ig, tc, ic, "mesh20k mode %d" % mode)
 
 
+def test_loop_strategy_tree(gpu, ra, orc):
+    """A tree built with KDTree::build(LOOP) (KDTree.cpp:54-127: axis cycles with the depth) serves the same query:
+    the device walks whatever tree the scene holds, the oracle walks its own LOOP restatement."""
+    s = meshgen.mesh_scene(3)
+    s.rebuild_tree(ra.HostScene.LOOP)
+    S = orc.OracleScene(s.raw())
+    S.rebuild(0)
+    assert s.n_nodes == S.n_nodes and s.depth == S.depth
+    gpu.upload(s.describe())
+    o, d, aux = meshgen.random_rays(200000, 77, s.n_objects)
+    last = np.random.default_rng(3).integers(-1, s.n_tris, o.shape[1]).astype(np.int32)
+    for mode, a in ((ra.MODE_UNCONDITIONAL, None), (ra.MODE_LAST_TID, last), (ra.MODE_NO_SELF, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = S.intersect(o, d, a, mode, threads=16)
+        m, ex = _check(tg, ig, tc, ic, "LOOP tree mode %d" % mode)
+        print("LOOP tree mode %d: id parity %.6f, t bit-equal %.6f" % (mode, m, ex))
+    S.close()
+    s.close()
+
+
 def test_stack_spill_levels(gpu, mesh20k, mesh20k_oracle, ra, monkeypatch):
     """Only the first levels of the per-lane stack live in LDS; with the cap forced down to 2 nearly
     every push goes through the global spill area and the answers must not change."""

@@ -91,6 +91,82 @@ def test_product_tree_equals_oracle_tree(cornell, cornell_oracle, mesh20k, mesh2
             assert np.array_equal(a[k], b[k]), k
 
 
+def test_loop_strategy_tree_equals_oracle_tree(ra, orc):
+    """KDTree::build(LOOP) (splitLoop, KDTree.cpp:54-127): the product's array build and the oracle's pointer
+    restatement agree bit for bit; the tree differs from BEST's, and building BEST again restores the loader's tree."""
+    s = meshgen.mesh_scene(3)
+    raw = s.raw()
+    o = orc.OracleScene(raw)
+    best = s.tree()
+    s.rebuild_tree(ra.HostScene.LOOP)
+    o.rebuild(0)
+    a, b = s.tree(), o.flatten()
+    assert s.n_nodes == o.n_nodes and s.depth == o.depth
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert s.n_nodes != len(best["node_right"]) or not np.array_equal(a["node_min"], best["node_min"])
+    # the root splits on x (dim 0), its children on y: the left child's max x is the median vertex x
+    xs = np.unique(raw["tris"].reshape(-1))
+    med = np.sort(raw["verts"][xs, 0])[len(xs) >> 1]
+    right = a["node_right"][0]
+    assert a["node_min"][right][0] > med  # every triangle on the right lies wholly beyond the split
+    s.rebuild_tree(ra.HostScene.BEST)
+    o.rebuild(1)
+    a, b = s.tree(), o.flatten()
+    for k in a:
+        assert np.array_equal(a[k], best[k]) and np.array_equal(a[k], b[k]), k
+    with pytest.raises(ra.MirtError, match="strategy"):
+        s.rebuild_tree(7)
+    s.close()
+    o.close()
+
+
+def test_shp_mesh_loads_like_the_reference(ra, tmp_path):
+    """SimpleShape::loadShape on a .shp file (SimpleShape.cpp:52-64): the two counts in the file are counts of
+    floats / of indices (saveShape, :341-357), and the reference resizes its vec3 lists to them, so the lists come out
+    three times too long with zero tails. The same mesh written as an .obj with those tails spelled out must load to
+    the same scene, bit for bit."""
+    rng = np.random.default_rng(5)
+    V = rng.uniform(-2, 3, (7, 3)).astype(np.float32)
+    F = np.array([[0, 1, 2], [2, 3, 4], [4, 5, 6], [6, 0, 3]], np.uint32)
+    with open(tmp_path / "m.shp", "wb") as f:
+        f.write(np.int32(V.size).tobytes() + V.tobytes() + np.int32(F.size).tobytes() + F.tobytes())
+    with open(tmp_path / "m.obj", "w") as f:
+        for v in V:
+            f.write("v %s %s %s\n" % tuple(repr(float(x)) for x in v))
+        for _ in range(2 * len(V)):
+            f.write("v 0 0 0\n")
+        for t in F:
+            f.write("f %d %d %d\n" % tuple(int(i) + 1 for i in t))
+        for _ in range(2 * len(F)):
+            f.write("f 1 1 1\n")
+    scene = """<Scene Name="S"><Camera Name="c"><width>8</width><height>4</height><sightDist>6</sightDist>
+      <focus>(0, 0, 0)</focus><position>(0, 0, 3)</position><up>(0, 1, 0)</up></Camera>
+      <Object><filePath>%s</filePath><Material><type>Diffuse</type><color>(0.1, 0.2, 0.3)</color></Material></Object>
+      </Scene>"""
+    raws = []
+    for ext in ("shp", "obj"):
+        (tmp_path / ("s_%s.xml" % ext)).write_text(scene % ("m." + ext))
+        (tmp_path / ("c_%s.xml" % ext)).write_text("<Config><Scene><path>s_%s.xml</path><name>S</name><camera>c</camera>"
+                                                   "</Scene><renderer>PT</renderer></Config>" % ext)
+        s = ra.HostScene.load_config(str(tmp_path / ("c_%s.xml" % ext)))
+        assert (s.n_verts, s.n_tris) == (3 * len(V), 3 * len(F))
+        raws.append((s.raw(), s.tree()))
+        s.close()
+    for k in ("verts", "tris", "tri_obj", "tri_local"):
+        assert np.array_equal(raws[0][0][k], raws[1][0][k]), k
+    for k in raws[0][1]:
+        assert np.array_equal(raws[0][1][k], raws[1][1][k]), k
+    # the zero tail is part of the unitize box (SimpleShape.cpp:183): the origin maps inside [-1, 1]^3
+    assert np.abs(raws[0][0]["verts"]).max() <= 1 + 1e-6
+    (tmp_path / "short.shp").write_bytes(np.int32(30).tobytes() + V.tobytes()[:40])
+    (tmp_path / "s_bad.xml").write_text(scene % "short.shp")
+    (tmp_path / "c_bad.xml").write_text("<Config><Scene><path>s_bad.xml</path><name>S</name><camera>c</camera></Scene>"
+                                        "<renderer>PT</renderer></Config>")
+    with pytest.raises(ra.MirtError, match="truncated"):
+        ra.HostScene.load_config(str(tmp_path / "c_bad.xml"))
+
+
 def test_describe_is_consistent(cornell, ra):
     d = cornell.describe()
     assert d.struct_size == C.sizeof(ra.SceneDesc) and d.n_tris == 1932 and d.n_objects == 8
