@@ -15,7 +15,14 @@ d = sys.argv[1]
 def short(name):
     name = re.sub(r"\(.*", "", name).replace("void ", "").replace("mirt::", "")
     return name[:70]
-print("# rocprofv3 summary of: python3 bench.py --steps N --warmup 1 --no-cpu --pt-spp 8 [--workload X] (scripts/profile_gpu.sh), directory %s" % d)
+cmd = None
+for line in open(os.path.join(d, "kt.log"), errors="replace") if os.path.exists(os.path.join(d, "kt.log")) else []:
+    m = re.search(r"\[rocprofv3\] '(.*)' ::", line)
+    if m:
+        cmd = re.sub(r"/\S*/repo/", "", m.group(1))
+print("# rocprofv3 summary of: %s (scripts/%s), directory %s" % (
+    cmd or "python3 bench.py --steps N --warmup 1 --no-cpu --pt-spp 8 [--workload X]",
+    "profile_pt.sh" if "ptprof" in d else "profile_gpu.sh", d))
 avg_us = {}
 for f in sorted(glob.glob(os.path.join(d, "kt", "*", "*_kernel_stats.csv")))[-1:]:
     print("\n## kernel trace --stats (per kernel: calls, total ms, average us, % of GPU time)")
