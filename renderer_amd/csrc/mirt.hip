@@ -812,7 +812,12 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
             vols[k].object = obj_trees[k].object;
             vols[k].first = (int)vnodes.size();
             vols[k].count = v.N;
-            vols[k].pad = 0;
+            // (MIRT_VOL_SMALL=0 in the environment: every object tree is walked, for A/B runs and the equality test)
+            const bool small_on = !getenv("MIRT_VOL_SMALL") || atoi(getenv("MIRT_VOL_SMALL")) != 0;
+            vols[k].small = small_on && s->objects[obj_trees[k].object].tri_count <= MIRT_VOL_SMALL ? 1 : 0;
+            std::vector<int> par(v.N, -1);
+            for (int i = 0; i < v.N; i++)
+                if (v.right[i] >= 0) par[i + 1] = par[v.right[i]] = vols[k].first + i;
             std::vector<int> after(v.N);  // the node that follows node i's subtree in pre-order (right[i] > i)
             for (int i = v.N - 1; i >= 0; i--) after[i] = v.right[i] < 0 ? i + 1 : after[v.right[i]];
             for (int i = 0; i < v.N; i++) {
@@ -824,7 +829,9 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
                 nd.hi = make_float4(v.mx[3 * i], v.mx[3 * i + 1], v.mx[3 * i + 2], 0.f);
                 nd.leaf_begin = v.right[i] < 0 ? slot_base + v.lbeg[i] : -1;
                 nd.leaf_end = v.right[i] < 0 ? slot_base + v.lend[i] : -1;
-                nd.pad[0] = nd.pad[1] = 0;
+                nd.parent = par[i];
+                nd.flat = (v.mn[3 * i] == v.mx[3 * i] || v.mn[3 * i + 1] == v.mx[3 * i + 1] ||
+                           v.mn[3 * i + 2] == v.mx[3 * i + 2]) ? 1 : 0;
                 vnodes.push_back(nd);
             }
             slot_base += s->objects[obj_trees[k].object].tri_count;
@@ -1798,6 +1805,10 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
     hipLaunchKernelGGL(k_generate, dim3((P + B - 1) / B), dim3(B), 0, st, cam, P, s0, prm->seed, cur->o,
                        cur->d, cur->stride, *cur, nee ? 2 : 1);
     HIPCHK(ctx, hipGetLastError());
+    if (ctx->sc.n_vols > 0) {  // Camera.cpp:35: the camera rays' inside object
+        hipLaunchKernelGGL(k_inside0, dim3((P + 255) / 256), dim3(256), 0, st, ctx->sc, cur->o, cur->d, cur->stride, P, cur->ids);
+        HIPCHK(ctx, hipGetLastError());
+    }
     auto timed_intersect = [&](int mode, PathBuf* pb, uint32_t n, const uint32_t* n_ptr, uint32_t* queue,
                                const uint32_t* off = nullptr) -> int {
         hipEvent_t e0 = get_event(ctx, *ev_used), e1 = get_event(ctx, *ev_used + 1);
@@ -1959,6 +1970,10 @@ static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderP
         hipLaunchKernelGGL(k_generate, dim3((P + B - 1) / B), dim3(B), 0, st, cam, P, prm->spp_begin + w * S, prm->seed, cur->o,
                            cur->d, cur->stride, *cur, 1, g << PID_GEN_SHIFT);
         HIPCHK(ctx, hipGetLastError());
+        if (ctx->sc.n_vols > 0) {  // Camera.cpp:35: the camera rays' inside object
+            hipLaunchKernelGGL(k_inside0, dim3((P + 255) / 256), dim3(256), 0, st, ctx->sc, cur->o, cur->d, cur->stride, P, cur->ids);
+            HIPCHK(ctx, hipGetLastError());
+        }
         auto timed_intersect = [&](int mode, PathBuf* pb, uint32_t n, const uint32_t* n_ptr, uint32_t* queue,
                                    const uint32_t* off = nullptr) -> int {
             hipEvent_t e0 = get_event(ctx, *ev_used), e1 = get_event(ctx, *ev_used + 1);

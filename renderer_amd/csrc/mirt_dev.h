@@ -119,13 +119,19 @@ struct DevLight {
 // memory per lane for every path of a scene that holds a medium.
 //   lo = (min.xyz, bits(escape)): the node that follows this node's whole subtree (VolRoot::first + count at the end)
 //   hi = (max.xyz, 0); leaf_begin / leaf_end: the leaf's triangle SLOTS (behind the scene's own), -1 for an inner node
+//   parent: index of the parent node in DevScene.vnodes (-1 for the root); flat: the box has zero extent along an axis
+// A SMALL tree (VolRoot::small: at most MIRT_VOL_SMALL triangles) is not walked at all: pt_kernels.h trace_small tests
+// every triangle and then the chain of boxes above the few that are hit.
 struct VolNode {
     float4 lo, hi;
-    int leaf_begin, leaf_end, pad[2];
+    int leaf_begin, leaf_end, parent, flat;
 };
 struct VolRoot {
-    int object, first, count, pad;  // nodes [first, first + count) of DevScene.vnodes
+    int object, first, count, small;  // nodes [first, first + count) of DevScene.vnodes
 };
+#ifndef MIRT_VOL_SMALL
+#define MIRT_VOL_SMALL 32
+#endif
 
 struct DevScene {
     const PairRec* pairs;  // breadth-first child pairs: the classifier-path traversal

@@ -243,13 +243,91 @@ __device__ inline float trace_object(const DevScene& sc, const VolRoot& R, f3 o,
     return best_slot >= 0 ? best : -1.f;
 }
 
+// Scene::findInsideObject's test of ONE small object (VolRoot::small, e.g. the 12 triangles of a fog cube): is the
+// object's own surface met from inside both backwards and forwards along the ray? The two unconditional closest-hit
+// queries of the reference (objKDTrees[i].intersect along -d and along d), computed the other way round and in one
+// pass: every triangle of the object is tested once - the three edge signs of the reference test are those of the
+// ray's LINE (negating d negates every sign exactly, and "all >= 0 or all <= 0" does not care), and the plane distance
+// along -d is exactly minus the one along d (n.(-d) = -(n.d), and IEEE division is odd) - so a triangle the line
+// passes through is a candidate of the forward query when q >= 0 and of the backward one when -q >= 0. Only for a
+// candidate that would become the closest hit of its query is the chain of boxes above it, its leaf up to the root,
+// put to the reference box test (decided by the slab classifier where that is proven, by the reference arithmetic
+// where not: the rule of k_verify). The reference's answer is the closest triangle among those whose whole chain
+// passes, later leaf / earlier triangle on a tie; walking the tree instead costs ~14 box tests of six IEEE divisions
+// each per query for a ray that starts inside a cube. (No distance pruning here, so the answer is the plain definition.)
+__device__ inline bool inside_small(const DevScene& sc, const VolRoot& R, f3 o, f3 d, const RayPre& pre) {
+    const f3 bd = neg(d);
+    RayPre preb = pre;
+    preb.inv = neg(pre.inv);  // RN(1 / -d) = -RN(1 / d)
+    RayPre2 q2;
+    q2.oxy = v2f{o.x, o.y};
+    q2.ozi = v2f{o.z, 0.f};
+    q2.dxy = v2f{d.x, d.y};
+    q2.dzc = v2f{d.z, 0.f};
+    float ft = -1.f, bt = -1.f;            // closest hit forwards / backwards
+    int fs = -1, bs = -1, fl = -1, bl = -1;  // its slot and leaf node
+    auto chain = [&](int leaf, f3 dir, const RayPre& p) {
+        for (int n = leaf; n >= 0;) {
+            const VolNode A = sc.vnodes[n];
+            int code = BOX_AMBIGUOUS;
+            float unused;
+            if (p.fast) code = slab_classify(A.lo, A.hi, A.flat != 0, o, p, unused);
+            if (code == BOX_MISS) return false;
+            if (code == BOX_AMBIGUOUS && !box_test(A.lo, A.hi, o, dir).hit) return false;
+            n = A.parent;
+        }
+        return true;
+    };
+    const int end = R.first + R.count;
+    for (int i = R.first; i < end; i++) {
+        const int lb = sc.vnodes[i].leaf_begin, le = sc.vnodes[i].leaf_end;  // (-1, -1 for an inner node)
+        for (int s = lb; s < le; s++) {
+            const TriRec T = sc.tris[s];
+            if (!tri_inside(T.x, T.y, T.z, q2)) continue;
+            // tri_plane (KDTree.cpp:283-288) for d; for -d the quotient changes its sign and nothing else
+            const f3 n = mk3(T.n.x, T.n.y, T.n.z);
+            const float dd = dot3(n, d);
+            if (dd == 0.f) continue;
+            const float q = dot3(n, tri_v2(T) - o) / dd, qb = -q;
+            if (!(q < 0.f) && q >= 0.f && (fs < 0 || q < ft || (q == ft && fl != i)) && chain(i, d, pre)) {
+                ft = q;
+                fs = s;
+                fl = i;
+            }
+            if (!(qb < 0.f) && qb >= 0.f && (bs < 0 || qb < bt || (qb == bt && bl != i)) && chain(i, bd, preb)) {
+                bt = qb;
+                bs = s;
+                bl = i;
+            }
+        }
+    }
+    if (bs < 0 || bt < 1e-6f || fs < 0 || ft < 1e-6f) return false;
+    VnRec V = sc.vns[bs];
+    f3 nn = shading_normal<true>(sc, sc.tris[bs], V, bs, o + bd * bt);
+    if (dot3(nn, bd) < 1e-6f) return false;
+    V = sc.vns[fs];
+    nn = shading_normal<true>(sc, sc.tris[fs], V, fs, o + d * ft);
+    return !(dot3(nn, d) < 1e-6f);
+}
+
 // the last volumetric object (other than `current`) whose own surface is met from inside both
 // backwards and forwards along the ray; -1 = none
-__device__ inline int find_inside(const DevScene& sc, f3 o, f3 d, int current) {
+#ifndef MIRT_X_FI_ATTR
+#define MIRT_X_FI_ATTR inline
+#endif
+__device__ MIRT_X_FI_ATTR int find_inside(const DevScene& sc, f3 o, f3 d, int current) {
+#ifdef MIRT_X_NOFIALL
+    return current < 0 ? sc.vols[sc.n_vols - 1].object : -1;
+#endif
     const f3 bd = neg(d);
+    const RayPre pre = ray_prepare(sc, o, d);
     for (int k = sc.n_vols - 1; k >= 0; k--) {
         const VolRoot R = sc.vols[k];
         if (R.object == current) continue;
+        if (R.small) {
+            if (inside_small(sc, R, o, d, pre)) return R.object;
+            continue;
+        }
         int slot = -1;
         float dist = trace_object(sc, R, o, bd, slot);
         if (dist < 1e-6f) continue;
@@ -264,6 +342,17 @@ __device__ inline int find_inside(const DevScene& sc, f3 o, f3 d, int current) {
         return R.object;
     }
     return -1;
+}
+
+// Camera.cpp:35: a camera ray's insideObject is findInsideObject(ray), asked when the ray is made. One lane per
+// camera ray of a wavefront, right after k_generate (scenes that hold a volumetric object only); the answer goes
+// into the path's packed ids, where k_shade reads every other path's inside object too.
+__global__ void __launch_bounds__(256)
+k_inside0(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, uint32_t stride, uint32_t n,
+          int* __restrict__ ids) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ids[i] = MIRT_PACK_IDS(-1, find_inside(sc, load3(O, stride, i), load3(D, stride, i), -1));
 }
 
 // ---- homogeneous medium helpers, SceneVPMObject.h:22-47 ----------------------------------------
@@ -674,7 +763,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
             pid = in.pid[i];
             Lg = L + (size_t)(pid >> PID_GEN_SHIFT) * 3u * (size_t)L_stride;
             int inside = unpack_inside(in.ids[i]);
-            if (VOL && depth == 0) inside = find_inside(sc, o, d, -1);  // Camera.cpp:35
+            // (a camera ray's inside object, Camera.cpp:35, was put there by k_inside0)
             const TriRec T = sc.tris[slot];
             const VnRec V = sc.vns[slot];
             const int hobj = __float_as_int(V.n0.w);
@@ -696,7 +785,11 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                 const DevObject vo = sc.objects[sobj];
                 // HomoMediaDistSampler.h:9-11, drawn before the case split
                 const float u = rng_float(key, ctr);
+#ifdef MIRT_X_FLOATMED
+                const float samp = -logf(1.f - u) / lum_y(sig_t(vo));
+#else
                 const float samp = (float)(-log(1.0 - (double)u) / (double)lum_y(sig_t(vo)));
+#endif
                 const bool go_in = (hobj == sobj) && (inside != sobj);
                 const bool be_in = (inside == sobj);
                 const bool out_of_vol = samp >= t;
@@ -734,8 +827,13 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                         cosTheta = ((1.f + vo.g * vo.g) - sqrTerm * sqrTerm) / (2.f * vo.g);
                     }
                     const float sinTheta = sqrtf(1.f - cosTheta * cosTheta);
+#ifdef MIRT_X_FLOATMED
+                    const float sinPhi = sinf(6.2831853f * e2);
+                    const float cosPhi = cosf(6.2831853f * e2);
+#else
                     const float sinPhi = (float)sin(2.0 * 3.14159265358979 * (double)e2);
                     const float cosPhi = (float)cos(2.0 * 3.14159265358979 * (double)e2);
+#endif
                     const f3 dir = to_world(lf, mk3(sinTheta * cosPhi, cosTheta, sinTheta * sinPhi));
                     const float ph = hg_value(vo.g, dot3(d, dir));
                     const f3 ds = mk3(vo.sigma_s[0], vo.sigma_s[1], vo.sigma_s[2]);

@@ -39,6 +39,27 @@ def test_balls_in_fog_image_parity(gpu, ra, orc):
     s.close()
 
 
+def test_small_object_tree_shortcut_equals_the_tree_walk(gpu, ra, monkeypatch):
+    """findInsideObject on a small object (the 12-triangle fog cube) tests the triangles first and only then the boxes
+    above the ones that are hit (pt_kernels.h inside_small); MIRT_VOL_SMALL=0 at upload makes it walk the object's tree
+    like any larger one. Same streams, same answers: the images are equal bit for bit, both integrators, and so are
+    the ray counts; camera inside (BallsInFog) and outside (a fog ball in the Cornell box) the medium."""
+    s = ra.HostScene.load_config(os.path.join(ROOT, "Data", "Config_Fog128.xml"))
+    cam = s.camera()
+    out = {}
+    for small in ("1", "0"):
+        monkeypatch.setenv("MIRT_VOL_SMALL", small)
+        gpu.upload(s.describe())
+        out[small] = (gpu.render_pt(cam, 24, seed=3), gpu.render_pttest(cam, 8, seed=3))
+    monkeypatch.delenv("MIRT_VOL_SMALL")
+    for k in (0, 1):
+        a, b = out["1"][k], out["0"][k]
+        assert np.array_equal(a[0], b[0]), float(np.abs(a[0] - b[0]).max())
+        assert int(a[1].n_rays) == int(b[1].n_rays)
+    assert out["1"][0][0].mean() > 0.01
+    s.close()
+
+
 def test_medium_known_answers_on_gpu(gpu, ra):
     """the closed forms of tests/test_oracle.py::test_medium_known_answers, on the device"""
     cam = ra.make_camera(32, 32, 400, position=(0, 0, 1), focus=(0, 0, -1))
