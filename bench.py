@@ -260,7 +260,10 @@ def path_tracing_section(dev, cam, scene_name, pt_spp, rank, world, barrier, sha
         tile = None
         s_begin, s_count = ra.shard_samples(pt_spp, world, rank)
         acc = torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda")
-    dev.render_tile_dev(cam, tile, acc.data_ptr(), min(s_count, 4), spp_begin=s_begin, seed=1)  # warm-up
+    # warm-up: a render long enough to make the library choose (and allocate) the wavefront width the timed render
+    # will use (chained renders of >= 4 x 128 Mi paths keep 128 Mi paths, ~30 GB, in flight: mirt.hip render_common)
+    px = (tile.width * tile.height) if tile is not None else wh
+    dev.render_tile_dev(cam, tile, acc.data_ptr(), min(s_count, 4 * max(1, (1 << 27) // px)), spp_begin=s_begin, seed=1)
     acc.zero_()
     barrier()
     t0 = time.perf_counter()

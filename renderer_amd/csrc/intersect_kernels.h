@@ -764,7 +764,14 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
                     redo = true;
                     break;
                 }
-                const NodeRec N = sc.rnodes[node];
+                // (the record as four 16-byte vectors and the jump entry chosen by selects: `N.jump[face]` on a struct
+                // copy made the compiler keep the six entries in LDS, written and read back with bank conflicts, which
+                // was 12 % of this kernel's wave cycles)
+                const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.rnodes + node);
+                struct { float4 lo, hi; } N;
+                N.lo = rec[0];
+                N.hi = rec[1];
+                const float4 j0 = rec[2], j1 = rec[3];  // jump[0..3], jump[4..5] + padding
                 if (COUNT) boxes++;
                 // most boxes of a chain are left through a face well clear of the box's edges: proven in ~25
                 // instructions; the rest (and every flat box) takes the full classifier, then the reference test
@@ -775,12 +782,15 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
                     // the reference accepts this box through that face, hence every ancestor that shares the face's
                     // plane bit for bit and is no narrower on the other two axes (NodeRec::jump): go on above them
                     const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-                    const int face = 2 * axis + (da > 0.f ? 1 : 0);
+                    // jump[2 * axis + (1 for the max plane)]: the ray leaves through the max plane when it runs upwards
+                    const float jlo = axis == 0 ? j0.x : (axis == 1 ? j0.z : j1.x);
+                    const float jhi = axis == 0 ? j0.y : (axis == 1 ? j0.w : j1.y);
+                    const int next = __float_as_int(da > 0.f ? jhi : jlo);
                     if (COUNT) {  // audit: every ancestor skipped must pass the reference test as well (must be 0)
-                        for (int a2 = __float_as_int(N.lo.w); a2 >= 0 && a2 != N.jump[face]; a2 = __float_as_int(sc.rnodes[a2].lo.w))
+                        for (int a2 = __float_as_int(N.lo.w); a2 >= 0 && a2 != next; a2 = __float_as_int(sc.rnodes[a2].lo.w))
                             if (!box_test(sc.rnodes[a2].lo, sc.rnodes[a2].hi, o, d).hit) atomicAdd(&counters[3], 1ull);
                     }
-                    node = N.jump[face];
+                    node = next;
                     continue;
                 }
                 float lb;

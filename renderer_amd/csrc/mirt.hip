@@ -2083,9 +2083,17 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     // samples/s on the Cornell scene, at ~18 GB of path state + L. A chained render has no such tail
     // (the survivors of the cut ride along with the next wavefront), so its default is 32 Mi paths
     // (~6 GB with the L ring and the carry buffer): 1305 Msamples/s against 1385 at 128 Mi.
+    // Round 3, the final kernels, 1024^2 x 1024 spp chained with 32 / 64 / 128 Mi paths in flight: 1 880 / 1 941 / 1 978
+    // Msamples/s (fog scene 1 753 / 1 808 / 1 842): fewer, larger launches and a quarter as many cuts. 128 Mi paths are
+    // ~30 GB of path state, carry buffer and L ring, a tenth of this GPU's memory, so a render long enough to fill at
+    // least four such wavefronts takes them, a shorter one 64 Mi, and 32 Mi below that.
     if (S == 0) {
-        const uint64_t wide = std::max<uint64_t>(1, (1ull << 27) / wh), narrow = std::max<uint64_t>(1, (1ull << 25) / wh);
-        S = (uint32_t)(can_chain && prm->spp_count > narrow ? narrow : wide);
+        const uint64_t wide = std::max<uint64_t>(1, (1ull << 27) / wh), mid = std::max<uint64_t>(1, (1ull << 26) / wh),
+                       narrow = std::max<uint64_t>(1, (1ull << 25) / wh);
+        if (!can_chain || prm->spp_count <= narrow) S = (uint32_t)wide;  // (a single wavefront, or none can be chained)
+        else if (prm->spp_count >= 4 * wide) S = (uint32_t)wide;
+        else if (prm->spp_count >= 4 * mid) S = (uint32_t)mid;
+        else S = (uint32_t)narrow;
     }
     S = std::min<uint32_t>(S, std::max<uint32_t>(prm->spp_count, 1));
     if (wh * S > (1ull << 30)) return fail(ctx, MIRT_E_LIMIT, "render: more than 2^30 paths per wavefront");
