@@ -803,29 +803,46 @@ float fastIntersect(const OrcScene& S, const GivenTree& T, const std::vector<int
             // face F, an ancestor whose plane on F is the same bit for bit and whose other two slabs are no narrower
             // is accepted through F by the very same t and point (KDTree.cpp:40-49), so the walk goes on above the run
             // of such ancestors (NodeRec::jump in renderer_amd/csrc/mirt_dev.h). Restated here with the accepted face
-            // of largest t found by the reference arithmetic itself; flat boxes never skip (the product's sufficient
-            // test cannot prove them).
-            int face = -1;
-            float tExit = -1;
+            // of largest t found by the reference arithmetic itself. A flat box (zero extent along an axis) accepted
+            // through that axis' plane, which is its min and its max plane at once, hands the acceptance on through
+            // either; the product follows the run that ends higher up.
             const bool flat = mn[0] == mx[0] || mn[1] == mx[1] || mn[2] == mx[2];
-            for (unsigned i = 0; i < 6 && !flat; i++) {
+            bool acc[6];
+            float dists[6];
+            for (unsigned i = 0; i < 6; i++) {
+                acc[i] = false;
+                dists[i] = -1;
                 if (ray.direction[i % 3] == 0) continue;
                 float plane = i < 3 ? mn[i] : mx[i - 3];
                 float dist = (plane - ray.origin[i % 3]) / ray.direction[i % 3];
                 V3 p = ray.origin + dist * ray.direction;
-                bool inter = dist >= 0 && mn[(i + 1) % 3] <= p[(i + 1) % 3] && mx[(i + 1) % 3] >= p[(i + 1) % 3] &&
-                             mn[(i + 2) % 3] <= p[(i + 2) % 3] && mx[(i + 2) % 3] >= p[(i + 2) % 3];
-                if (inter && dist > tExit) tExit = dist, face = (int)i;
+                acc[i] = dist >= 0 && mn[(i + 1) % 3] <= p[(i + 1) % 3] && mx[(i + 1) % 3] >= p[(i + 1) % 3] &&
+                         mn[(i + 2) % 3] <= p[(i + 2) % 3] && mx[(i + 2) % 3] >= p[(i + 2) % 3];
+                dists[i] = dist;
             }
+            auto runAbove = [&](int face) {  // first ancestor that does not inherit an acceptance through `face`
+                int next = refParent[node];
+                while (next >= 0) {
+                    const int a = face % 3;
+                    const float cp = face < 3 ? mn[a] : mx[a], pp = face < 3 ? S.fmin[next][a] : S.fmax[next][a];
+                    bool inherits = std::memcmp(&cp, &pp, 4) == 0;
+                    for (int b : {(a + 1) % 3, (a + 2) % 3})
+                        inherits = inherits && S.fmin[next][b] <= mn[b] && S.fmax[next][b] >= mx[b];
+                    if (!inherits) break;
+                    next = refParent[next];
+                }
+                return next;
+            };
             int next = refParent[node];
-            while (face >= 0 && next >= 0) {
-                const int a = face % 3;
-                const float cp = face < 3 ? mn[a] : mx[a], pp = face < 3 ? S.fmin[next][a] : S.fmax[next][a];
-                bool inherits = std::memcmp(&cp, &pp, 4) == 0;
-                for (int b : {(a + 1) % 3, (a + 2) % 3})
-                    inherits = inherits && S.fmin[next][b] <= mn[b] && S.fmax[next][b] >= mx[b];
-                if (!inherits) break;
-                next = refParent[next];
+            if (flat) {
+                for (int a = 0; a < 3; a++)
+                    if (mn[a] == mx[a] && acc[a] && acc[a + 3]) next = std::min(next, std::min(runAbove(a), runAbove(a + 3)));
+            } else {
+                int face = -1;
+                float tExit = -1;
+                for (int i = 0; i < 6; i++)
+                    if (acc[i] && dists[i] > tExit) tExit = dists[i], face = i;
+                if (face >= 0) next = runAbove(face);
             }
             node = next;
         }

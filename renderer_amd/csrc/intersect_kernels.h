@@ -773,10 +773,11 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
                 N.hi = rec[1];
                 const float4 j0 = rec[2], j1 = rec[3];  // jump[0..3], jump[4..5] + padding
                 if (COUNT) boxes++;
-                // most boxes of a chain are left through a face well clear of the box's edges: proven in ~25
-                // instructions; the rest (and every flat box) takes the full classifier, then the reference test
+                // most boxes of a chain are left through a face well clear of the box's edges, or are flat and crossed
+                // well inside: proven in ~30 instructions; the rest takes the full classifier, then the reference test
                 int axis;
-                if (slab_exit_face_proven(N.lo, N.hi, c, pre, axis)) {
+                bool via_flat;
+                if (slab_face_proven(N.lo, N.hi, __float_as_int(N.hi.w) != 0, c, pre, axis, via_flat)) {
                     if (COUNT && !box_test(N.lo, N.hi, o, d).hit)
                         atomicAdd(&counters[3], 1ull);  // audit: a proven exit face the reference test does not share (must be 0)
                     // the reference accepts this box through that face, hence every ancestor that shares the face's
@@ -785,7 +786,9 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
                     // jump[2 * axis + (1 for the max plane)]: the ray leaves through the max plane when it runs upwards
                     const float jlo = axis == 0 ? j0.x : (axis == 1 ? j0.z : j1.x);
                     const float jhi = axis == 0 ? j0.y : (axis == 1 ? j0.w : j1.y);
-                    const int next = __float_as_int(da > 0.f ? jhi : jlo);
+                    // (a flat box's accepted plane is its min and its max plane: either run of inheriting ancestors is
+                    // proven, so the one that ends higher up - the smaller node index, -1 = above the root - is taken)
+                    const int next = via_flat ? min(__float_as_int(jlo), __float_as_int(jhi)) : __float_as_int(da > 0.f ? jhi : jlo);
                     if (COUNT) {  // audit: every ancestor skipped must pass the reference test as well (must be 0)
                         for (int a2 = __float_as_int(N.lo.w); a2 >= 0 && a2 != next; a2 = __float_as_int(sc.rnodes[a2].lo.w))
                             if (!box_test(sc.rnodes[a2].lo, sc.rnodes[a2].hi, o, d).hit) atomicAdd(&counters[3], 1ull);

@@ -467,6 +467,27 @@ __device__ __forceinline__ bool slab_exit_face_proven(const float4 lo, const flo
     axis = fx == tf ? 0 : (fy == tf ? 1 : 2);
     return (tf > M) & (tf - tn > M) & (f2 - tf > M);
 }
+// The same with the flat boxes' case folded in (every axis-aligned wall triangle's leaf, and the node above two of
+// them): a box of zero extent along an axis yields that axis' entry and exit parameter from the same plane by the same
+// fused multiply-add, bit for bit, so tn == tf means that the one face is entry and exit at once and both other slabs
+// contain it; the reference accepts that face when it lies in front of the origin (tf > M) and is clear of the other
+// axes' entries (tn - n2 > M) and exits (f2 - tf > M): slab_classify's rule for flat boxes with this function's
+// parameters. `via_flat`: the accepted plane is the box's min AND max plane on `axis`, so the run of ancestors that
+// inherit the acceptance may be followed through either (k_verify takes the longer run).
+__device__ __forceinline__ bool slab_face_proven(const float4 lo, const float4 hi, bool flat, f3 c, const RayPre& p,
+                                                 int& axis, bool& via_flat) {
+    const float t0x = __builtin_fmaf(lo.x, p.inv.x, c.x), t1x = __builtin_fmaf(hi.x, p.inv.x, c.x);
+    const float t0y = __builtin_fmaf(lo.y, p.inv.y, c.y), t1y = __builtin_fmaf(hi.y, p.inv.y, c.y);
+    const float t0z = __builtin_fmaf(lo.z, p.inv.z, c.z), t1z = __builtin_fmaf(hi.z, p.inv.z, c.z);
+    const float fx = fmaxf(t0x, t1x), fy = fmaxf(t0y, t1y), fz = fmaxf(t0z, t1z);
+    const float nx = fminf(t0x, t1x), ny = fminf(t0y, t1y), nz = fminf(t0z, t1z);
+    const float tn = fmaxf(nx, fmaxf(ny, nz)), n2 = __builtin_amdgcn_fmed3f(nx, ny, nz);
+    const float tf = fminf(fx, fminf(fy, fz)), f2 = __builtin_amdgcn_fmed3f(fx, fy, fz);
+    const float M = __builtin_fmaf(1.9073486e-06f /*32 * 2^-24*/, fabsf(tn) + fabsf(tf), p.a_ray);
+    axis = fx == tf ? 0 : (fy == tf ? 1 : 2);
+    via_flat = flat & (tn == tf) & (tn - n2 > M);
+    return (tf > M) & (f2 - tf > M) & ((tf - tn > M) | via_flat);
+}
 __device__ __forceinline__ bool box_is_flat(const float4 lo, const float4 hi) {
     return (lo.x == hi.x) | (lo.y == hi.y) | (lo.z == hi.z);
 }
