@@ -841,20 +841,23 @@ constexpr int RERUN_STACK = 2048;
 // ray (the slowest ray's ~200 dependent exact box tests); the wave-wide time grows with count / 1024 waves, the other
 // barely, and they cross near 10^4 rays.
 constexpr uint32_t RERUN_WIDE_MAX = 8192;
-template <bool SLOT_OUT, int MODE = MIRT_MODE_NO_SELF>
+// ANYHIT: the visibility query's re-run (launch_visibility): vis_out = 1 unless the closest legal hit lies nearer than
+// limit by more than EPSILON, which is "some legal hit does" because the rounded difference is monotone in t.
+template <bool SLOT_OUT, int MODE = MIRT_MODE_NO_SELF, bool ANYHIT = false>
 __global__ void __launch_bounds__(64)
 k_rerun(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, const int* __restrict__ aux,
         uint32_t plane_stride, float* __restrict__ t_out, int* __restrict__ id_out,
         const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count, uint32_t list_max,
-        const uint32_t* __restrict__ off_ptr = nullptr) {
+        const uint32_t* __restrict__ off_ptr = nullptr, const float* __restrict__ limit = nullptr,
+        unsigned char* __restrict__ vis_out = nullptr) {
     __shared__ int stack[RERUN_STACK];
     if (off_ptr) {
         const uint32_t off = *off_ptr;
         O += off;
         D += off;
         if (aux) aux += off;
-        t_out += off;
-        id_out += off;
+        if (t_out) t_out += off;
+        if (id_out) id_out += off;
     }
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -941,7 +944,9 @@ k_rerun(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, c
                 best_leaf = ol;
             }
         }
-        if (lane == 0) {
+        if (ANYHIT) {
+            if (lane == 0) vis_out[idx] = (best_slot >= 0 && best - limit[idx] < -1e-5f) ? 0 : 1;
+        } else if (lane == 0) {
             t_out[idx] = best_slot >= 0 ? best : -1.f;
             if (SLOT_OUT)
                 id_out[idx] = best_slot;

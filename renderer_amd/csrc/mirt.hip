@@ -1389,10 +1389,21 @@ static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const f
         hipLaunchKernelGGL((k_verify<true, false>), dim3((n + 255) / 256), dim3(256), 0, st, ctx->sc, O, D, n, n_ptr, stride,
                            (const float*)nullptr, ctx->d_vis_slot, ctx->d_fb_list, queue + 1, ctx->d_counters);
         HIPCHK(ctx, hipGetLastError());
+        // the listed rays on the reference tree: one wave per ray for a short list (k_rerun, as for the closest hit: the
+        // lane-per-ray kernel lasts as long as its slowest ray's ~200 dependent exact box tests, 83 us per bounce of a
+        // PathTracerTest render against 25), the lane-per-ray exact kernel for a long one; each returns at once when
+        // the list is the other's
+        static const bool rerun_wide = !getenv("MIRT_RERUN_WIDE") || atoi(getenv("MIRT_RERUN_WIDE")) != 0;  // A/B switch
+        if (rerun_wide) {
+            hipLaunchKernelGGL((k_rerun<false, MIRT_MODE_NO_SELF, true>), dim3(std::min<uint32_t>(n, 1024)), dim3(64), 0, st,
+                               ctx->sc, O, D, aux, stride, (float*)nullptr, (int*)nullptr, (const uint32_t*)ctx->d_fb_list,
+                               (const uint32_t*)(queue + 1), RERUN_WIDE_MAX, (const uint32_t*)nullptr, limit, vis_out);
+            HIPCHK(ctx, hipGetLastError());
+        }
         hipLaunchKernelGGL((k_intersect<MIRT_MODE_NO_SELF, false, false, true>), grid, block, ctx->lds_main, st, ctx->sc,
                            O, D, aux, n, (const uint32_t*)(queue + 1), stride, (float*)nullptr, (int*)nullptr,
                            ctx->d_counters, queue + 2, ctx->lds_levels, ctx->d_spill, limit, vis_out,
-                           (const uint32_t*)ctx->d_fb_list);
+                           (const uint32_t*)ctx->d_fb_list, rerun_wide ? RERUN_WIDE_MAX : 0u);
         HIPCHK(ctx, hipGetLastError());
         return MIRT_OK;
     }
