@@ -2111,8 +2111,16 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     if (nee) S = std::min<uint32_t>(S, (uint32_t)std::max<uint64_t>(1, (1ull << 26) / wh));
     const bool chained = can_chain && prm->spp_count > S;
     if (chained) {
-        const size_t carry_cap = (size_t)(wh * S) / 4;
-        rc = ensure_paths(ctx, (size_t)(wh * S) + carry_cap, (int)(prm->max_depth / chain_cut(prm->max_depth)) + 1, carry_cap);
+        // (a width the library chose itself is halved, down to 32 Mi paths, when the device cannot hold it: another
+        // context's buffers, a smaller GPU)
+        const uint32_t narrow = (uint32_t)std::max<uint64_t>(1, (1ull << 25) / wh);
+        for (;;) {
+            const size_t carry_cap = (size_t)(wh * S) / 4;
+            rc = ensure_paths(ctx, (size_t)(wh * S) + carry_cap, (int)(prm->max_depth / chain_cut(prm->max_depth)) + 1, carry_cap);
+            if (rc == MIRT_OK || prm->spp_per_launch != 0 || S <= narrow) break;
+            (void)hipGetLastError();
+            S = std::max(narrow, S / 2);
+        }
     } else {
         rc = ensure_paths(ctx, (size_t)(wh * S));
     }
