@@ -1946,7 +1946,8 @@ static uint32_t chain_cut(uint32_t max_depth) {
 }
 
 static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderParams* prm, uint32_t S, float* rgb_sum,
-                       uint64_t* n_rays, size_t* ev_used, MirtRenderStats* stats) {
+                       uint64_t* n_rays, size_t* ev_used, MirtRenderStats* stats, bool nee = false,
+                       uint64_t* n_shadow = nullptr) {
     const uint32_t wh = (uint32_t)cam.tw * (uint32_t)cam.th;  // pixels of the window being rendered
     const uint32_t cut = chain_cut(prm->max_depth);
     const int gens = (int)(prm->max_depth / cut) + 1;
@@ -1978,8 +1979,12 @@ static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderP
         HIPCHK(ctx, hipMemsetAsync(ctx->d_cnt, 0, words * sizeof(uint32_t), st));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_ab, 0, 64 * words * sizeof(uint32_t), st));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_wq, 0, 3 * words * sizeof(uint32_t), st));
+        if (nee) {
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_ns, 0, words * sizeof(uint32_t), st));
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_wq2, 0, 3 * words * sizeof(uint32_t), st));
+        }
         hipLaunchKernelGGL(k_generate, dim3((P + B - 1) / B), dim3(B), 0, st, cam, P, prm->spp_begin + w * S, prm->seed, cur->o,
-                           cur->d, cur->stride, *cur, 1, g << PID_GEN_SHIFT);
+                           cur->d, cur->stride, *cur, nee ? 2 : 1, g << PID_GEN_SHIFT);
         HIPCHK(ctx, hipGetLastError());
         if (ctx->sc.n_vols > 0) {  // Camera.cpp:35: the camera rays' inside object
             hipLaunchKernelGGL(k_inside0, dim3((P + 255) / 256), dim3(256), 0, st, ctx->sc, cur->o, cur->d, cur->stride, P, cur->ids);
@@ -2017,7 +2022,22 @@ static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderP
             uint32_t* ab = ctx->d_ab + 64 * (size_t)(it + 1);
             // two-ended compaction (pt_kernels.h, k_shade<.., TWO>): survivors land in [mid - ab[32], mid + ab[0])
             const uint32_t sgrid = (bound + SHADE_BLOCK - 1) / SHADE_BLOCK, mid = (sgrid >> 1) * (uint32_t)SHADE_BLOCK;
-            if (ctx->has_media)
+            if (nee) {
+                // PathTracerTest (as in run_wavefront): one shadow ray per RANDOM vertex, the visibility launch and
+                // k_connect before the next bounce touches L; a carried path scores into its own wavefront's buffer
+                uint32_t* n_sh = ctx->d_ns + it;
+                if (ctx->has_media)
+                    hipLaunchKernelGGL((k_shade<true, true, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in,
+                                       bound, *nxt, ab, ctx->d_L, (uint32_t)cap, prm->max_depth, ctx->shb, n_sh, off_in);
+                else
+                    hipLaunchKernelGGL((k_shade<false, true, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in,
+                                       bound, *nxt, ab, ctx->d_L, (uint32_t)cap, prm->max_depth, ctx->shb, n_sh, off_in);
+                HIPCHK(ctx, hipGetLastError());
+                const int rcv = launch_visibility(ctx, st, MIRT_MODE_NO_SELF, ctx->shb.o, ctx->shb.d, ctx->shb.ids, ctx->shb.lim,
+                                                  bound, ctx->shb.stride, ctx->shb.vis, n_sh, ctx->d_wq2 + 3 * it);
+                if (rcv != MIRT_OK) return rcv;
+                hipLaunchKernelGGL(k_connect, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->shb, n_sh, bound, ctx->d_L, (uint32_t)cap);
+            } else if (ctx->has_media)
                 hipLaunchKernelGGL((k_shade<true, false, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
                                    ab, ctx->d_L, (uint32_t)cap, prm->max_depth, ShadowBuf{}, (uint32_t*)nullptr, off_in);
             else
@@ -2053,6 +2073,11 @@ static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderP
         HIPCHK(ctx, hipStreamSynchronize(st));
         *n_rays += P;
         for (uint32_t k = 1; k < depths_run + 1 && k <= prm->max_depth; k++) *n_rays += ctx->h_cnt[k];
+        if (nee && n_shadow) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, ctx->d_ns, depths_run * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            for (uint32_t k = 0; k < depths_run; k++) *n_shadow += ctx->h_cnt[k];
+        }
         if (*ev_used > 4096) {  // fold the event pool so long renders do not grow it without bound
             if (stats)
                 for (size_t k = 2; k + 1 < *ev_used; k += 2) {
@@ -2087,7 +2112,7 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     uint32_t S = prm->spp_per_launch;
     // plain path tracing over several wavefronts: chained (run_chained); MIRT_CHAIN=0 switches it off (A/B)
     static const bool chain_on = !getenv("MIRT_CHAIN") || atoi(getenv("MIRT_CHAIN")) != 0;
-    const bool can_chain = chain_on && !nee && !cap && rgb_sum_dev && chain_cut(prm->max_depth) < prm->max_depth &&
+    const bool can_chain = chain_on && !cap && rgb_sum_dev && chain_cut(prm->max_depth) < prm->max_depth &&
                            prm->max_depth / chain_cut(prm->max_depth) + 1 <= 4;
     // Each bounce is one launch and the late bounces of a wavefront are latency-bound (a few thousand
     // paths, ~0.2 ms each), so an unchained wavefront wants to be wide: 16 Mi -> 128 Mi paths is +25 %
@@ -2108,7 +2133,13 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     }
     S = std::min<uint32_t>(S, std::max<uint32_t>(prm->spp_count, 1));
     if (wh * S > (1ull << 30)) return fail(ctx, MIRT_E_LIMIT, "render: more than 2^30 paths per wavefront");
-    if (nee) S = std::min<uint32_t>(S, (uint32_t)std::max<uint64_t>(1, (1ull << 26) / wh));
+    // PathTracerTest (shadow-ray buffers beside the path state): at most 64 Mi paths per wavefront; a render that fits
+    // one such wavefront stays one (1024^2 x 64 spp: 1 097 Msamples/s against 1 069 as two chained wavefronts of 32 Mi),
+    // a longer one is chained at that width (512 spp: 1 145 against ~1 100 unchained)
+    if (nee) {
+        const uint32_t nee_cap = (uint32_t)std::max<uint64_t>(1, (1ull << 26) / wh);
+        S = prm->spp_per_launch ? std::min(S, nee_cap) : std::min<uint32_t>(nee_cap, std::max<uint32_t>(prm->spp_count, 1));
+    }
     const bool chained = can_chain && prm->spp_count > S;
     if (chained) {
         // (a width the library chose itself is halved, down to 32 Mi paths, when the device cannot hold it: another
@@ -2125,8 +2156,8 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
         rc = ensure_paths(ctx, (size_t)(wh * S));
     }
     if (rc != MIRT_OK) return rc;
-    if (nee) {
-        rc = ensure_shadow(ctx, (size_t)(wh * S));
+    if (nee) {  // (a chained wavefront also shades the paths carried over from the one before)
+        rc = ensure_shadow(ctx, (size_t)(wh * S) + (chained ? (size_t)(wh * S) / 4 : 0));
         if (rc != MIRT_OK) return rc;
     }
     uint64_t n_shadow = 0;
@@ -2136,7 +2167,7 @@ static int render_common(MirtContext* ctx, const MirtRenderParams* prm, float* r
     uint64_t n_rays = 0;
     HIPCHK(ctx, hipEventRecord(t0, ctx->stream));
     if (chained) {
-        rc = run_chained(ctx, cam, prm, S, rgb_sum_dev, &n_rays, &ev_used, stats);
+        rc = run_chained(ctx, cam, prm, S, rgb_sum_dev, &n_rays, &ev_used, stats, nee, &n_shadow);
         if (rc != MIRT_OK) return rc;
     } else
     for (uint32_t done = 0; done < prm->spp_count; done += S) {

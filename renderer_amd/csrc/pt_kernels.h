@@ -1052,6 +1052,7 @@ k_connect(ShadowBuf sh, const uint32_t* __restrict__ n_ptr, uint32_t n_max, floa
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n || !sh.vis[j]) return;
     const uint32_t pid = sh.pid[j] & PID_MASK;
+    L += (size_t)(sh.pid[j] >> PID_GEN_SHIFT) * 3u * (size_t)L_stride;  // the radiance buffer of the path's own wavefront (L ring)
     L[pid] += sh.c[j];
     L[L_stride + pid] += sh.c[sh.stride + j];
     L[2 * L_stride + pid] += sh.c[2 * sh.stride + j];
@@ -1098,6 +1099,7 @@ k_carry(PathBuf src, const uint32_t* __restrict__ n_src, uint32_t n_max, PathBuf
     dst.ctr[j] = src.ctr[i];
     dst.ids[j] = src.ids[i];
     dst.pid[j] = src.pid[i];
+    if (src.lpw && dst.lpw) dst.lpw[j] = src.lpw[i];  // (PathTracerTest: the density of the last sampled direction)
 }
 
 // two-ended compaction (k_shade<.., TWO>): length and start of the range the two counters describe

@@ -85,21 +85,22 @@ def test_determinism_sharding_and_batching(gpu, cornell, ra):
     assert not np.array_equal(a, d)
 
 
-def _chained_vs_separate(dev, cam, spp, spl, max_depth, seed=5):
+def _chained_vs_separate(dev, cam, spp, spl, max_depth, seed=5, pttest=False):
     """one call over several wavefronts (chained: run_chained in mirt.hip) against one call per wavefront
-    into the same accumulator (each a single, unchained wavefront): same bits, same ray count"""
+    into the same accumulator (each a single, unchained wavefront): same bits, same ray (and shadow-ray) count"""
     import torch
+    render = dev.render_pttest_dev if pttest else dev.render_pt_dev
     a = torch.zeros(cam.height, cam.width, 3, device="cuda")
-    st = dev.render_pt_dev(cam, a.data_ptr(), spp, max_depth=max_depth, seed=seed, spp_per_launch=spl)
+    st = render(cam, a.data_ptr(), spp, max_depth=max_depth, seed=seed, spp_per_launch=spl)
     b = torch.zeros_like(a)
-    rays = 0
+    rays = shadow = 0
     for begin in range(0, spp, spl):
-        s = dev.render_pt_dev(cam, b.data_ptr(), min(spl, spp - begin), spp_begin=begin, max_depth=max_depth,
-                              seed=seed, spp_per_launch=spl)
+        s = render(cam, b.data_ptr(), min(spl, spp - begin), spp_begin=begin, max_depth=max_depth, seed=seed, spp_per_launch=spl)
         rays += int(s.n_rays)
+        shadow += int(s.n_shadow_rays)
     torch.cuda.synchronize()
-    assert torch.equal(a, b), (max_depth, spl, float((a - b).abs().max()))
-    assert int(st.n_rays) == rays and st.n_samples == cam.width * cam.height * spp
+    assert torch.equal(a, b), (max_depth, spl, pttest, float((a - b).abs().max()))
+    assert int(st.n_rays) == rays and int(st.n_shadow_rays) == shadow and st.n_samples == cam.width * cam.height * spp
     return a
 
 
@@ -113,6 +114,9 @@ def test_chained_wavefronts_equal_separate_wavefronts(gpu, cornell, ra):
     cam = cornell.camera()
     for md, spl in ((20, 3), (7, 2), (6, 2), (40, 4), (100, 5), (250, 2)):
         _chained_vs_separate(gpu, cam, 4 * spl + 1, spl, md)
+    for md, spl in ((20, 3), (7, 2), (40, 4)):  # PathTracerTest is chained as well (round 3): connections included
+        img = _chained_vs_separate(gpu, cam, 4 * spl + 1, spl, md, pttest=True)
+        assert float(img.mean()) > 0.1
     with pytest.raises(ra.MirtError, match="max_depth"):
         gpu.render_pt(cam, 1, max_depth=251)
     m = meshgen.cornell_with_meshes(2)
@@ -130,7 +134,14 @@ def test_chained_wavefronts_equal_separate_wavefronts(gpu, cornell, ra):
     alive = gpu.capture_rays_dev(cam, 4, 6, 6, o.data_ptr(), d.data_ptr(), aux.data_ptr(), P, seed=5)
     assert alive > P // 4, alive  # (else this scene does not exercise the skipped cut)
     _chained_vs_separate(gpu, cam, 14, 4, 20)
+    _chained_vs_separate(gpu, cam, 14, 4, 20, pttest=True)
     s.close()
+    # and inside a medium, both integrators
+    f = ra.HostScene.load_config(os.path.join(ROOT, "Data", "Config_Fog128.xml"))
+    gpu.upload(f.describe())
+    _chained_vs_separate(gpu, f.camera(), 9, 2, 20)
+    _chained_vs_separate(gpu, f.camera(), 9, 2, 20, pttest=True)
+    f.close()
 
 
 def test_depth_cap_and_edge_sizes(gpu, cornell, cornell_oracle, ra):
