@@ -196,7 +196,8 @@ def closest_hit_section(workload, args, rank, world, local, barrier, tstream, wa
         ks = prof["kernels"]
         # one closest-hit call in the predicate mode = fast-tree launch + k_verify + exact re-run
         names = [n for n in sorted(ks) if n.startswith("k_intersect<2, false, false, false, true")
-                 or n.startswith("k_verify<false, false") or n.startswith("k_rerun<false, 2")]
+                 or n.startswith("k_verify<false, false")
+                 or (n.startswith("k_rerun<false, 2") and not n.endswith(", true>"))]  # (not the visibility query's re-run)
     if names and n_sec == N_SECONDARY and sec_ms > 0 and all(ks[n].get("avg_us") for n in names):
         prof_ms = sum(ks[n]["avg_us"] for n in names) / 1e3
         main = ks[names[0]]
