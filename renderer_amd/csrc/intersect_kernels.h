@@ -725,12 +725,15 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
 // A and is therefore A's winner too (same total order: t, then the slot tie rule). Anything else, and
 // every ray outside the classifier's error model, goes on the list the exact kernel re-runs.
 // SLOT_OUT false: a confirmed slot is replaced by its global triangle id. counters[0] += box tests.
-template <bool SLOT_OUT, bool COUNT>
+// CONNECT (the visibility query of PathTracerTest): a ray with no occluder in the superset is visible, finally: its
+// pending light connection is added to its path's radiance here (ConnectArgs, mirt_dev.h).
+template <bool SLOT_OUT, bool COUNT, bool CONNECT = false>
 __global__ void __launch_bounds__(256)
 k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, uint32_t n_direct,
          const uint32_t* __restrict__ n_ptr, uint32_t plane_stride, const float* __restrict__ t_out,
          int* __restrict__ id_out, uint32_t* __restrict__ list, uint32_t* __restrict__ list_count,
-         unsigned long long* __restrict__ counters, const uint32_t* __restrict__ off_ptr = nullptr) {
+         unsigned long long* __restrict__ counters, const uint32_t* __restrict__ off_ptr = nullptr,
+         ConnectArgs ca = ConnectArgs{}) {
     const uint32_t n = n_ptr ? min(*n_ptr, n_direct) : n_direct;
     if (off_ptr) {  // (as in k_intersect; the list holds indices from there on, and k_rerun counts from there too)
         const uint32_t off = *off_ptr;
@@ -805,8 +808,9 @@ k_verify(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, 
                 node = __float_as_int(N.lo.w);
             }
             if (!redo && !SLOT_OUT) id_out[i] = __float_as_int(sc.vns[slot].n1.w);
-        } else if (!SLOT_OUT) {
-            id_out[i] = -1;
+        } else {
+            if (!SLOT_OUT) id_out[i] = -1;
+            if (CONNECT) connect_add(ca, i);
         }
     }
     // wave-aggregated append
@@ -953,6 +957,25 @@ k_rerun(DevScene sc, const float* __restrict__ O, const float* __restrict__ D, c
             else
                 id_out[idx] = best_slot >= 0 ? __float_as_int(sc.vns[best_slot].n1.w) : -1;
         }
+    }
+}
+
+// every visible shadow ray's light connection (the visibility routes without k_verify: no fast tree, bump textures)
+__global__ void __launch_bounds__(256)
+k_connect_all(ConnectArgs ca, const unsigned char* __restrict__ vis, const uint32_t* __restrict__ n_ptr, uint32_t n_max) {
+    const uint32_t n = n_ptr ? min(*n_ptr, n_max) : n_max;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n && vis[j]) connect_add(ca, j);
+}
+
+// the light connections of the shadow rays the visibility query re-ran (their answers are in vis now)
+__global__ void __launch_bounds__(256)
+k_connect_list(ConnectArgs ca, const unsigned char* __restrict__ vis, const uint32_t* __restrict__ list,
+               const uint32_t* __restrict__ list_count) {
+    const uint32_t count = *list_count;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < count; r += gridDim.x * blockDim.x) {
+        const uint32_t j = list[r];
+        if (vis[j]) connect_add(ca, j);
     }
 }
 

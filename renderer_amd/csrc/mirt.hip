@@ -1359,9 +1359,12 @@ static int launch_intersect(MirtContext* ctx, hipStream_t st, int mode, const fl
 // visibility variant: vis_out[i] = 1 unless a legal hit lies nearer than limit[i]. `queue`: THREE zeroed words
 // owned by this call (as in launch_intersect). In the predicate mode with a fast tree: any-hit walk of the
 // fast tree, k_verify on the occluders it found, exact any-hit kernel for the rays k_verify listed.
+// connect != nullptr (PathTracerTest): the pending light connections of the rays that turn out visible are added to
+// their paths' radiance before this returns (by the query's own kernels on the fast route, by k_connect_all otherwise).
 static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const float* O, const float* D,
                              const int* aux, const float* limit, uint32_t n, uint32_t stride,
-                             unsigned char* vis_out, const uint32_t* n_ptr = nullptr, uint32_t* queue = nullptr) {
+                             unsigned char* vis_out, const uint32_t* n_ptr = nullptr, uint32_t* queue = nullptr,
+                             const ConnectArgs* connect = nullptr) {
     if (n == 0) return MIRT_OK;
     const uint32_t want = (n + ctx->block - 1) / ctx->block;
     dim3 block(ctx->block), grid(std::min<uint32_t>(want, (uint32_t)ctx->max_blocks));
@@ -1386,8 +1389,13 @@ static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const f
                            ctx->sc, O, D, aux, n, n_ptr, stride, (float*)nullptr, ctx->d_vis_slot, ctx->d_counters, queue,
                            ctx->lds_levels_fast, ctx->d_spill, limit, vis_out);
         HIPCHK(ctx, hipGetLastError());
-        hipLaunchKernelGGL((k_verify<true, false>), dim3((n + 255) / 256), dim3(256), 0, st, ctx->sc, O, D, n, n_ptr, stride,
-                           (const float*)nullptr, ctx->d_vis_slot, ctx->d_fb_list, queue + 1, ctx->d_counters);
+        if (connect)
+            hipLaunchKernelGGL((k_verify<true, false, true>), dim3((n + 255) / 256), dim3(256), 0, st, ctx->sc, O, D, n, n_ptr, stride,
+                               (const float*)nullptr, ctx->d_vis_slot, ctx->d_fb_list, queue + 1, ctx->d_counters,
+                               (const uint32_t*)nullptr, *connect);
+        else
+            hipLaunchKernelGGL((k_verify<true, false>), dim3((n + 255) / 256), dim3(256), 0, st, ctx->sc, O, D, n, n_ptr, stride,
+                               (const float*)nullptr, ctx->d_vis_slot, ctx->d_fb_list, queue + 1, ctx->d_counters);
         HIPCHK(ctx, hipGetLastError());
         // the listed rays on the reference tree: one wave per ray for a short list (k_rerun, as for the closest hit: the
         // lane-per-ray kernel lasts as long as its slowest ray's ~200 dependent exact box tests, 83 us per bounce of a
@@ -1405,6 +1413,11 @@ static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const f
                            ctx->d_counters, queue + 2, ctx->lds_levels, ctx->d_spill, limit, vis_out,
                            (const uint32_t*)ctx->d_fb_list, rerun_wide ? RERUN_WIDE_MAX : 0u);
         HIPCHK(ctx, hipGetLastError());
+        if (connect) {  // the re-run rays' connections (a short list; a long one is walked by the same few blocks)
+            hipLaunchKernelGGL(k_connect_list, dim3(64), dim3(256), 0, st, *connect, (const unsigned char*)vis_out,
+                               (const uint32_t*)ctx->d_fb_list, (const uint32_t*)(queue + 1));
+            HIPCHK(ctx, hipGetLastError());
+        }
         return MIRT_OK;
     }
 #define MIRT_VIS(MODE)                                                                                        \
@@ -1426,6 +1439,10 @@ static int launch_visibility(MirtContext* ctx, hipStream_t st, int mode, const f
     }
 #undef MIRT_VIS
     HIPCHK(ctx, hipGetLastError());
+    if (connect) {
+        hipLaunchKernelGGL(k_connect_all, dim3((n + 255) / 256), dim3(256), 0, st, *connect, (const unsigned char*)vis_out, n_ptr, n);
+        HIPCHK(ctx, hipGetLastError());
+    }
     return MIRT_OK;
 }
 
@@ -1850,7 +1867,7 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
         const uint32_t sgrid = (bound + SHADE_BLOCK - 1) / SHADE_BLOCK, mid = (sgrid >> 1) * (uint32_t)SHADE_BLOCK;
         if (nee) {
             // PathTracerTest: shade writes one shadow ray per RANDOM vertex; the visibility launch and
-            // k_connect add the unoccluded contributions before the next bounce touches L again
+            // its kernels add the unoccluded contributions before the next bounce touches L again
             uint32_t* n_sh = ctx->d_ns + depth;
             if (ctx->has_media)
                 hipLaunchKernelGGL((k_shade<true, true, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur,
@@ -1861,11 +1878,10 @@ static int run_wavefront(MirtContext* ctx, const DevCamera& cam, const MirtRende
                                    n_in, bound, *nxt, ab, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth,
                                    ctx->shb, n_sh, off_in);
             HIPCHK(ctx, hipGetLastError());
+            const ConnectArgs ca{ctx->shb.c, ctx->shb.stride, ctx->shb.pid, ctx->d_L, (uint32_t)ctx->pb_cap, PID_MASK, (uint32_t)PID_GEN_SHIFT};
             int rcv = launch_visibility(ctx, st, MIRT_MODE_NO_SELF, ctx->shb.o, ctx->shb.d, ctx->shb.ids, ctx->shb.lim,
-                                        bound, ctx->shb.stride, ctx->shb.vis, n_sh, ctx->d_wq2 + 3 * depth);
+                                        bound, ctx->shb.stride, ctx->shb.vis, n_sh, ctx->d_wq2 + 3 * depth, &ca);
             if (rcv != MIRT_OK) return rcv;
-            hipLaunchKernelGGL(k_connect, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->shb, n_sh, bound, ctx->d_L,
-                               (uint32_t)ctx->pb_cap);
         } else if (ctx->has_media)
             hipLaunchKernelGGL((k_shade<true, false, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in,
                                bound, *nxt, ab, ctx->d_L, (uint32_t)ctx->pb_cap, prm->max_depth, ShadowBuf{},
@@ -2024,7 +2040,7 @@ static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderP
             const uint32_t sgrid = (bound + SHADE_BLOCK - 1) / SHADE_BLOCK, mid = (sgrid >> 1) * (uint32_t)SHADE_BLOCK;
             if (nee) {
                 // PathTracerTest (as in run_wavefront): one shadow ray per RANDOM vertex, the visibility launch and
-                // k_connect before the next bounce touches L; a carried path scores into its own wavefront's buffer
+                // its connections before the next bounce touches L; a carried path scores into its own wavefront's buffer
                 uint32_t* n_sh = ctx->d_ns + it;
                 if (ctx->has_media)
                     hipLaunchKernelGGL((k_shade<true, true, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in,
@@ -2033,10 +2049,10 @@ static int run_chained(MirtContext* ctx, const DevCamera& cam, const MirtRenderP
                     hipLaunchKernelGGL((k_shade<false, true, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in,
                                        bound, *nxt, ab, ctx->d_L, (uint32_t)cap, prm->max_depth, ctx->shb, n_sh, off_in);
                 HIPCHK(ctx, hipGetLastError());
+                const ConnectArgs ca{ctx->shb.c, ctx->shb.stride, ctx->shb.pid, ctx->d_L, (uint32_t)cap, PID_MASK, (uint32_t)PID_GEN_SHIFT};
                 const int rcv = launch_visibility(ctx, st, MIRT_MODE_NO_SELF, ctx->shb.o, ctx->shb.d, ctx->shb.ids, ctx->shb.lim,
-                                                  bound, ctx->shb.stride, ctx->shb.vis, n_sh, ctx->d_wq2 + 3 * it);
+                                                  bound, ctx->shb.stride, ctx->shb.vis, n_sh, ctx->d_wq2 + 3 * it, &ca);
                 if (rcv != MIRT_OK) return rcv;
-                hipLaunchKernelGGL(k_connect, dim3((bound + B - 1) / B), dim3(B), 0, st, ctx->shb, n_sh, bound, ctx->d_L, (uint32_t)cap);
             } else if (ctx->has_media)
                 hipLaunchKernelGGL((k_shade<true, false, true>), dim3(sgrid), dim3(SHADE_BLOCK), 0, st, ctx->sc, cam, *cur, n_in, bound, *nxt,
                                    ab, ctx->d_L, (uint32_t)cap, prm->max_depth, ShadowBuf{}, (uint32_t*)nullptr, off_in);

@@ -133,6 +133,26 @@ struct VolRoot {
 #define MIRT_VOL_SMALL 32
 #endif
 
+// PathTracerTest's light connections (pt_kernels.h k_shade<NEE>): the pending contribution c[j] of shadow ray j is added
+// to its path's radiance L[pid] when the ray turns out unoccluded. The visibility query's own kernels do that where
+// they learn the answer (k_verify for a ray with no occluder in the fast tree's superset, k_connect_list for the few
+// rays that were re-run), so the shadow rays are not streamed through a kernel of their own once more.
+struct ConnectArgs {
+    const float* c;       // [3][c_stride] pending contributions
+    uint32_t c_stride;
+    const uint32_t* pid;  // path id of the shadow ray; the bits from gen_shift up select the buffer of the L ring
+    float* L;             // [gens][3][L_stride]
+    uint32_t L_stride, pid_mask, gen_shift;
+};
+__device__ __forceinline__ void connect_add(const ConnectArgs& a, uint32_t j) {
+    const uint32_t p = a.pid[j];
+    float* L = a.L + (size_t)(p >> a.gen_shift) * 3u * (size_t)a.L_stride;
+    const uint32_t px = p & a.pid_mask;
+    L[px] += a.c[j];
+    L[a.L_stride + px] += a.c[a.c_stride + j];
+    L[2 * a.L_stride + px] += a.c[2 * a.c_stride + j];
+}
+
 struct DevScene {
     const PairRec* pairs;  // breadth-first child pairs: the classifier-path traversal
     float4 root_lo, root_hi;  // root box; root_lo.w = bits(link of the root)

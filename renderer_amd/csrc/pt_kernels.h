@@ -45,7 +45,7 @@ __device__ __forceinline__ void shift_paths(PathBuf& b, uint32_t off) {
 }
 
 // Shadow rays of one bounce of PathTracerTest (colorByConnectingLights, PathTracerTest.cpp:85-135):
-// what the visibility launch reads (o, d, ids, lim) and what k_connect adds to L when unoccluded.
+// what the visibility launch reads (o, d, ids, lim) and what the visibility query adds to L when unoccluded (ConnectArgs).
 struct ShadowBuf {
     float* o;       // [3][stride]
     float* d;       // [3][stride]
@@ -127,7 +127,7 @@ k_generate(DevCamera cam, uint32_t n, uint32_t spp_begin, uint32_t seed, float* 
     // the same nodes and test the same triangles, their hits have one material and one triangle record (k_verify,
     // k_shade at depth 0). Streams and radiance slots are keyed by (pixel, sample): the image does not depend on it.
     // 1024^2 x 1024 spp: 1 994 -> 2 021 Msamples/s (fog scene 1 841 -> 1 856).
-    // (plain path tracing only: PathTracerTest adds a light connection to L[pid] at every bounce, and k_connect's
+    // (plain path tracing only: PathTracerTest adds a light connection to L[pid] at every bounce, and the connection's
     // read-modify-write of entries a whole image apart is slower than the traversal gains: 1 107 -> 971 Msamples/s)
     if (fill_state == 1) {
         const uint32_t s_cnt = n / wh;  // samples per pixel in this wavefront (n = wh * s_cnt)
@@ -681,7 +681,7 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
 // reference's `throughput` there (no originProb, no camera cosine, no vignetting compensation), an
 // emitter hit is weighted against the light connection that could have found it, and every RANDOM
 // vertex writes one shadow ray + its pending contribution to `sh` (compacted like the paths); the
-// visibility launch and k_connect finish it. With VOL the estimator is the reference's inside media too: light
+// visibility launch finishes it (ConnectArgs). With VOL the estimator is the reference's inside media too: light
 // connections from scattering events through the phase function, and NO division by originProb (PathTracerTest.cpp:70-74).
 #ifndef MIRT_SHADE_OCTANT
 #define MIRT_SHADE_OCTANT 1
@@ -1061,20 +1061,9 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
     }
 }
 
-// Adds the pending contribution of every unoccluded light connection to its path's radiance
-// (PathTracerTest.cpp:62 after MCRenderer::testVisibility, PathTracerTest.cpp:97-98). One shadow ray
-// per path and bounce, so no two lanes touch the same L entry.
-__global__ void __launch_bounds__(256)
-k_connect(ShadowBuf sh, const uint32_t* __restrict__ n_ptr, uint32_t n_max, float* __restrict__ L, uint32_t L_stride) {
-    const uint32_t n = min(*n_ptr, n_max);
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n || !sh.vis[j]) return;
-    const uint32_t pid = sh.pid[j] & PID_MASK;
-    L += (size_t)(sh.pid[j] >> PID_GEN_SHIFT) * 3u * (size_t)L_stride;  // the radiance buffer of the path's own wavefront (L ring)
-    L[pid] += sh.c[j];
-    L[L_stride + pid] += sh.c[sh.stride + j];
-    L[2 * L_stride + pid] += sh.c[2 * sh.stride + j];
-}
+// (The pending contribution of an unoccluded light connection is added to its path's radiance, PathTracerTest.cpp:62
+// after MCRenderer::testVisibility and :97-98, by the visibility query's own kernels: ConnectArgs in mirt_dev.h. One
+// shadow ray per path and bounce, so no two lanes touch the same L entry.)
 
 // rgb_sum[p] = (..((rgb_sum[p] + L_0) + L_1) + ..): the launch's samples are added ONE BY ONE, in sample order, to what
 // the accumulator already holds, so the image is the same fp32 sum however the samples are cut into wavefronts
