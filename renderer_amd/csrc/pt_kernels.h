@@ -683,8 +683,15 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
 // vertex writes one shadow ray + its pending contribution to `sh` (compacted like the paths); the
 // visibility launch finishes it (ConnectArgs). With VOL the estimator is the reference's inside media too: light
 // connections from scattering events through the phase function, and NO division by originProb (PathTracerTest.cpp:70-74).
+// Order of a block's survivors in the next bounce's buffer: 0 = as the waves hold them (each wave writes one contiguous
+// run), 1 = by the octant of the new direction across the block, 2 = by octant inside each wave. Round 1 introduced 1
+// (+1.6 % then). With round 3's kernels and wavefront widths the large k_shade launches run at HBM speed, where the
+// scattered stores of 1 cost more than the ordering gives the traversal: 1024^2 x 1024 spp 2 002 (1) / 2 066 (2) / 2 089 (0)
+// Msamples/s, 24 spp 1 671 / - / 1 722, PathTracerTest 1 106 / - / 1 132, time inside the traversal launches equal. A batch
+// captured from the path tracer and handed to mirt_intersect_dev is traced 3 % faster with 1 (Cornell bounce batch
+// 1.62 against 1.68 ms): an order a caller may give its own batches, not one the path tracer should pay for.
 #ifndef MIRT_SHADE_OCTANT
-#define MIRT_SHADE_OCTANT 1
+#define MIRT_SHADE_OCTANT 0
 #endif
 #ifndef MIRT_SHADE_BIN
 #define MIRT_SHADE_BIN 1
@@ -987,7 +994,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) s_wcnt[w] = __popcll(m);
-#if MIRT_SHADE_OCTANT
+#if MIRT_SHADE_OCTANT == 1
     // survivors of a block leave ordered by the octant of their new direction: the next traversal's waves
     // (which take consecutive rays) then hold rays that agree on the order in which children are visited
     __shared__ uint32_t s_oct[SHADE_WAVES][8];
@@ -997,6 +1004,18 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
         const unsigned long long mk = __ballot(alive && oct == k);
         if (lane == 0) s_oct[w][k] = __popcll(mk);
         if (k == oct) in_wave_before = __popcll(mk & ((1ull << lane) - 1ull));
+    }
+#elif MIRT_SHADE_OCTANT == 2
+    // the same inside each wave only: a wave's survivors stay one contiguous run (whole lines stored), ordered by octant
+    {
+        const int oct = (nd.x < 0.f ? 1 : 0) | (nd.y < 0.f ? 2 : 0) | (nd.z < 0.f ? 4 : 0);
+        uint32_t before = 0, mine = 0;
+        for (int k = 0; k < 8; k++) {
+            const unsigned long long mk = __ballot(alive && oct == k);
+            if (k < oct) before += __popcll(mk);
+            if (k == oct) mine = __popcll(mk & ((1ull << lane) - 1ull));
+        }
+        rank = before + mine;
     }
 #endif
     const unsigned long long m2 = NEE ? __ballot(shadow) : 0ull;
@@ -1018,7 +1037,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
             s_base2 = tot2 ? atomicAdd(n_sh, tot2) : 0u;
         }
     }
-#if MIRT_SHADE_OCTANT
+#if MIRT_SHADE_OCTANT == 1
     // (s_off is free again: every thread read its entry of the material sort before the barriers above)
     if (threadIdx.x < SHADE_WAVES * 8) {
         const uint32_t k = threadIdx.x / SHADE_WAVES, w2 = threadIdx.x % SHADE_WAVES;
@@ -1043,7 +1062,7 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
     }
     if (alive) {
         uint32_t wb = 0;
-#if MIRT_SHADE_OCTANT
+#if MIRT_SHADE_OCTANT == 1
         wb = s_off[w][oct];
         rank = in_wave_before;
 #else
