@@ -46,11 +46,14 @@ print("%-40s sec %.3f ms (%.0f Mrays/s)  pri %.3f ms (%.0f Mrays/s)  total %.0f 
     os.path.basename(os.environ.get("MIRT_LIB", "libmirt.so")), ms2, n_sec / ms2 / 1e3, ms0, n_pri / ms0 / 1e3,
     (n_sec + n_pri) / (ms0 + ms2) / 1e3, chk), flush=True)
 if os.environ.get("AUDIT"):
+    # (the audit entry point instruments the EXACT route unless MIRT_AUDIT_FAST is set: the product's route is the fast
+    # one. `box` then holds the fast tree's tests, two per pair step, + k_verify's chain tests, a few per ray.)
+    os.environ.setdefault("MIRT_AUDIT_FAST", "1")
     a = dev.intersect_audit_dev(so.data_ptr(), sd.data_ptr(), sa.data_ptr(), n_sec, 2, t1.data_ptr(), i1.data_ptr())
     print(a)
-    print("inner lane util %.3f  leaf lane util %.3f  inner wave-steps/ray-lane %.2f  outer/ray-lane %.2f" % (
-        (a["box"] / 2) / (64.0 * a["wave_inner"]), a["tri"] / (64.0 * a["wave_leaf"]),
-        64.0 * a["wave_inner"] / n_sec, 64.0 * a["wave_outer"] / n_sec))
+    print("per ray: box tests %.1f  triangle tests %.2f;  per 64 rays: node passes %.1f  leaf passes %.1f;  "
+          "leaf pass lanes %.1f of 64" % (a["box"] / n_sec, a["tri"] / n_sec, 64.0 * a["wave_inner"] / n_sec,
+                                          64.0 * a["wave_leaf"] / n_sec, a["tri"] / a["wave_leaf"]))
 if os.environ.get("SORTEXP"):
     # experiment: how much does ray coherence buy? reorder the secondary batch by several keys
     n = n_sec
