@@ -616,7 +616,20 @@ BoxRes boxOrdered(const V3& minC, const V3& maxC, const KRay& ray) {
     r.lb = lb;
     return r;
 }
-inline bool pruned(float lb, bool have, float best) { return have && lb > best * 1.0001f + 1e-5f; }
+// (mirt_dev.h exact_prune_slack: how far in front of its leaf's box the reference's t can lie for a ray that barely
+// moves along an axis; the same fp32 operations in the same order)
+float exactPruneSlack(const OrcScene& S, const KRay& ray) {
+    float m = 0;
+    for (int a = 0; a < 3; a++) {
+        float ia = std::fabs(1.0f / ray.direction[a]);
+        if (!(ia < INFINITY)) continue;
+        float bound = std::max(std::fabs(S.fmin[0][a]), std::fabs(S.fmax[0][a]));
+        float v = (std::fabs(ray.origin[a]) + bound) * ia;
+        m = v > m ? v : m;
+    }
+    return 1.9073486328125e-06f * m;
+}
+inline bool pruned(float lb, bool have, float best, float slack) { return have && lb > best * 1.0001f + 1e-5f + slack; }
 
 float orderedIntersect(const OrcScene& S, const KRay& ray, const Condition& cond, int& slotOut,
                        Counters& cnt) {
@@ -627,6 +640,7 @@ float orderedIntersect(const OrcScene& S, const KRay& ray, const Condition& cond
         float lb;
     };
     std::vector<E> stack;
+    const float slack = exactPruneSlack(S, ray);
     cnt.box++;
     if (!boxOrdered(S.fmin[0], S.fmax[0], ray).hit) {
         slotOut = -1;
@@ -654,8 +668,8 @@ float orderedIntersect(const OrcScene& S, const KRay& ray, const Condition& cond
             cnt.box += 2;
             BoxRes bl = boxOrdered(S.fmin[L], S.fmax[L], ray);
             BoxRes br = boxOrdered(S.fmin[R], S.fmax[R], ray);
-            bool hl = bl.hit && !pruned(bl.lb, bestSlot >= 0, best);
-            bool hr = br.hit && !pruned(br.lb, bestSlot >= 0, best);
+            bool hl = bl.hit && !pruned(bl.lb, bestSlot >= 0, best, slack);
+            bool hr = br.hit && !pruned(br.lb, bestSlot >= 0, best, slack);
             if (hl && hr) {
                 if (bl.lb <= br.lb) {
                     stack.push_back({R, br.lb});
@@ -677,7 +691,7 @@ float orderedIntersect(const OrcScene& S, const KRay& ray, const Condition& cond
             while (!stack.empty()) {
                 E e = stack.back();
                 stack.pop_back();
-                if (pruned(e.lb, bestSlot >= 0, best)) continue;
+                if (pruned(e.lb, bestSlot >= 0, best, slack)) continue;
                 cur = e.node;
                 found = true;
                 break;
@@ -762,8 +776,8 @@ float fastIntersect(const OrcScene& S, const GivenTree& T, const std::vector<int
             cnt.box += 2;
             BoxRes bl = boxConservative(T.lo(L), T.hi(L), ray);
             BoxRes br = boxConservative(T.lo(R), T.hi(R), ray);
-            bool hl = bl.hit && !pruned(bl.lb, bestSlot >= 0, best);
-            bool hr = br.hit && !pruned(br.lb, bestSlot >= 0, best);
+            bool hl = bl.hit && !pruned(bl.lb, bestSlot >= 0, best, 0.f);
+            bool hr = br.hit && !pruned(br.lb, bestSlot >= 0, best, 0.f);
             if (hl && hr) {
                 if (bl.lb <= br.lb) {
                     stack.push_back({R, br.lb});
@@ -785,7 +799,7 @@ float fastIntersect(const OrcScene& S, const GivenTree& T, const std::vector<int
             while (!stack.empty()) {
                 E e = stack.back();
                 stack.pop_back();
-                if (pruned(e.lb, bestSlot >= 0, best)) continue;
+                if (pruned(e.lb, bestSlot >= 0, best, 0.f)) continue;
                 cur = e.node;
                 found = true;
                 break;

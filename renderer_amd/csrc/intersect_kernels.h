@@ -244,6 +244,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     // The entry distances themselves are slab_miss_pair's one-FMA parameters, each off by up to 3/16 a_ray (far from
     // the origin that is much more than the prune slack: |o| = 300, 1/d = 13 gives 1e-3), so thr carries a_ray / 2.
     float cur_lb = 0.f;
+    float xslack = 0.f;  // exact kernels: exact_prune_slack() of this ray
     int best_slot = -1, link = 0;
     uint32_t sp = 0;  // stack depth as the BYTE offset of the next free LDS level (level * blockDim * 8)
     int leaf_pos = 0, leaf_end = 0;  // triangles still to test in the current leaf
@@ -308,7 +309,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
         }
         best = t;
         best_slot = s;
-        thr = FAST ? __builtin_fmaf(fmaxf(t, cur_lb), 1.0001f, 1e-5f + 0.5f * pre.a_ray) : t * 1.0001f + 1e-5f;
+        thr = FAST ? __builtin_fmaf(fmaxf(t, cur_lb), 1.0001f, 1e-5f + 0.5f * pre.a_ray) : t * 1.0001f + 1e-5f + xslack;
     };
 
     // The fast-tree kernels (incoherent rays, deep walks) take the vote loop; the exact kernels (camera rays on small
@@ -388,8 +389,10 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 active = true;
                 pre = ray_prepare(sc, o, d);
                 pre2 = ray_pairs(o, d, pre);
-                // nothing beyond the limit can occlude (+ the rounding of this kernel's entry distances, see cur_lb)
-                if (ANYHIT) thr = __builtin_fmaf(lim, 1.0001f, 1e-5f + 0.5f * pre.a_ray);
+                // nothing beyond the limit can occlude (+ the rounding of this kernel's entry distances, see cur_lb, and
+                // the reach of the reference's edge signs in t, the exact kernels' exact_prune_slack: 2 a_ray for a ray
+                // that takes this route)
+                if (ANYHIT) thr = __builtin_fmaf(lim, 1.0001f, 1e-5f + 2.f * pre.a_ray);
                 float lb;
                 const int code = slab_classify(root_lo, root_hi, box_is_flat(root_lo, root_hi), o, pre, lb);
                 if (FAST) {
@@ -566,7 +569,6 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 thr = INF;
                 if (ANYHIT) {
                     lim = limit[idx];
-                    thr = lim * 1.0001f + 1e-5f;  // nothing beyond the limit can occlude
                     occluded = false;
                 }
                 best_slot = -1;
@@ -576,6 +578,8 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
                 active = true;
                 pre = ray_prepare(sc, o, d);
                 pre2 = ray_pairs(o, d, pre);
+                xslack = exact_prune_slack(sc, o, pre);
+                if (ANYHIT) thr = lim * 1.0001f + 1e-5f + xslack;  // nothing beyond the limit can occlude
                 float lb;
                 const int code = slab_classify(root_lo, root_hi, box_is_flat(root_lo, root_hi), o, pre, lb);
                 if (resolve(root_lo, root_hi, code, lb)) enter(__float_as_int(root_lo.w));

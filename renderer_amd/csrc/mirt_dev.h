@@ -316,6 +316,23 @@ __device__ __forceinline__ RayPre ray_prepare(const DevScene& sc, f3 o, f3 d) {
     return p;
 }
 
+// Absolute slack of the EXACT kernels' prune (k_intersect's while-while loop). The reference prunes nothing; these
+// kernels skip a box that starts beyond the closest hit's t. The reference's edge signs (KDTree.cpp:267-289) accept a
+// line that passes a triangle's edge on the wrong side by ~16 eps |v - o|, so an accepted hit can lie that far outside
+// the triangle, hence outside the leaf boxes that list it; along an axis the ray barely moves on (|1/d_a| large) that
+// is 16 eps |v - o| |1/d_a| in t: a ray with d_z = 3e-6 aimed at a triangle's corner had its hit 0.3 in front of the
+// leaf's box (found by scripts/fuzz_campaign.py in the visibility query, whose limit sits right behind the hit). This
+// is a_ray without the axes the ray does not move along at all (1/d_a infinite: there the box test is a containment
+// test and no t depends on it), doubled because |v - o| is a norm where a_ray takes one axis.
+__device__ __forceinline__ float exact_prune_slack(const DevScene& sc, f3 o, const RayPre& p) {
+    const float INF = __builtin_inff();
+    const float ix = fabsf(p.inv.x), iy = fabsf(p.inv.y), iz = fabsf(p.inv.z);
+    const float ax = ix < INF ? (fabsf(o.x) + sc.bound[0]) * ix : 0.f;
+    const float ay = iy < INF ? (fabsf(o.y) + sc.bound[1]) * iy : 0.f;
+    const float az = iz < INF ? (fabsf(o.z) + sc.bound[2]) * iz : 0.f;
+    return 1.9073486328125e-06f /*32 * 2^-24*/ * fmaxf(ax, fmaxf(ay, az));
+}
+
 __device__ __forceinline__ int slab_classify(const float4 lo, const float4 hi, bool flat, f3 o,
                                              const RayPre& p, float& lb) {
     const float t0x = (lo.x - o.x) * p.inv.x, t1x = (hi.x - o.x) * p.inv.x;

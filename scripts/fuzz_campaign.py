@@ -1,6 +1,7 @@
 """One-off differential fuzz campaign on the GPU box (not part of the test suite): many random triangle soups of
 random size, scale and position against the CPU oracle, closest hit in the three modes + visibility.
-usage: python scripts/fuzz_campaign.py first_seed n_seeds [rays]   (prints one line per seed, details of differing rays)"""
+usage: python scripts/fuzz_campaign.py first_seed n_seeds [rays]   (prints one line per seed, details of differing rays;
+SEEDS=a,b,c in the environment replaces the range)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -13,7 +14,8 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
 dev = ra.Device(device=0)
 total = bad = 0
 t0 = time.time()
-for seed in range(first, first + count):
+seeds = [int(x) for x in os.environ["SEEDS"].split(",")] if os.environ.get("SEEDS") else range(first, first + count)
+for seed in seeds:
     rng = np.random.default_rng(seed)
     n_tri = int(10 ** rng.uniform(0.5, 4.3))
     scale = float(10 ** rng.uniform(-3, 3))

@@ -141,6 +141,39 @@ def test_triangle_soup_visibility_against_oracle(gpu, ra, orc, seed, n_tri):
     scene.close()
 
 
+@pytest.mark.parametrize("seed", [8072, 8094, 8227, 8267, 8301, 8358])
+def test_corner_rays_that_barely_move_along_an_axis(gpu, ra, orc, seed):
+    """scripts/fuzz_campaign.py's soups of these seeds each hold a ray with one direction component of 1e-6 .. 1e-4
+    aimed at a corner of a well-shaped triangle: the reference's edge signs accept the hit although the ray's line
+    passes the corner ~1e-6 outside, which along that axis is 1e-2 .. 0.3 in t IN FRONT of every box that lists the
+    triangle, and the exact kernels' prune (mode 0 takes them: the limit sits right behind the hit) skipped those
+    boxes until it got exact_prune_slack (mirt_dev.h). Bit-equal flags in mode 0 now; the fast route (mode 2) always
+    carried the ray's margin."""
+    n = 150000
+    rng = np.random.default_rng(seed)  # (the campaign's recipe, draw for draw)
+    n_tri = int(10 ** rng.uniform(0.5, 4.3))
+    scale = float(10 ** rng.uniform(-3, 3))
+    offset = tuple((rng.uniform(-1, 1, 3) * scale * 10 ** rng.uniform(-1, 1.5)).tolist()) if rng.random() < 0.6 else (0.0, 0.0, 0.0)
+    n_obj = int(rng.integers(1, 7)) if n_tri >= 40 else 1
+    scene, v = _soup(ra, rng, n_tri, n_obj, scale, offset)
+    S = orc.OracleScene(scene.raw())
+    gpu.upload(scene.describe())
+    o, d, aux, last = _rays(rng, v, n, n_obj, ra, scale, offset, scene.raw()["tri_obj"])
+    for mode, a in ((0, None), (1, last), (2, aux)):  # (the campaign's draws in between: none, these are queries)
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = S.intersect(o, d, a, mode, threads=16)
+        assert np.array_equal(ig, ic) and np.array_equal(tg, tc, equal_nan=True), mode
+    tc, ic = S.intersect(o, d, aux, 2, threads=16)
+    lim = np.where(ic >= 0, tc, scale).astype(np.float32)
+    lim = (lim * rng.choice(np.array([0.5, 1.0 - 1e-6, 1.0, 1.0 + 1e-6, 1.0 + 1e-4, 2.0, 100.0], np.float32), n)).astype(np.float32)
+    for mode, a in ((2, aux), (0, None)):
+        vg = gpu.visibility(o, d, a, lim, mode)
+        vc = S.visibility(o, d, a, lim, mode, threads=16)
+        assert np.array_equal(vg, vc), (mode, np.nonzero(vg != vc)[0][:5])
+    S.close()
+    scene.close()
+
+
 @pytest.mark.parametrize("seed,n_tri,scale,offset", [(21, 3000, 1.0, (0, 0, 0)), (22, 3000, 25.0, (300.0, -120.0, 75.0)),
                                                     (23, 800, 1e-3, (0.0, 0.0, 0.0))])
 def test_soup_bounce_and_edge_parallel_rays(gpu, ra, orc, seed, n_tri, scale, offset):
