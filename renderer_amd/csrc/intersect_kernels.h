@@ -236,7 +236,7 @@ k_intersect(DevScene sc, const float* __restrict__ O, const float* __restrict__ 
     uint32_t idx = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
     int a = 0;
-    float best = -1.f, thr = INF;  // thr: entry distances beyond it cannot beat the closest hit (prune())
+    float best = -1.f, thr = INF;  // thr: entry distances beyond it cannot beat the closest hit
     // FAST: entry distance of the box being visited. A fast-tree leaf is one triangle's own box, and the reference's
     // t = orthoDist / (n.d) of a sliver (an fp32 plane normal off by 1e-3) or of a grazing hit can lie IN FRONT of that
     // box by more than the prune slack; pruning against such a t would skip the triangle's twin in a tie, or a triangle

@@ -529,12 +529,6 @@ __device__ __forceinline__ bool box_is_flat(const float4 lo, const float4 hi) {
     return (lo.x == hi.x) | (lo.y == hi.y) | (lo.z == hi.z);
 }
 
-// a subtree whose box starts beyond the closest accepted hit cannot change the result; the slack
-// covers the rounding of t (plane equation) against lb (slab quotients).
-__device__ __forceinline__ bool prune(float lb, bool have, float best) {
-    return have && lb > best * 1.0001f + 1e-5f;
-}
-
 // ---- triangle test (KDTree.cpp:267-289) ----------------------------------------------------------
 // In two parts, each the reference's operations in the reference's order (no contraction), so the pair is the
 // reference test bit for bit: tri_inside() is the three edge signs (the ray's line passes through the triangle),

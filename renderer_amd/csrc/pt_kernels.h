@@ -235,7 +235,10 @@ __device__ __forceinline__ float vignette_div(const DevCamera& c, uint32_t pixel
 // (KDTree.cpp:34-52) on every node whose parent passed, in pre-order with escape indices instead of a stack. The
 // reference visits both children of every node it enters and keeps the smallest t (later leaf on a tie, earlier
 // triangle inside a leaf: KDTree.cpp:305, 319-320); the order of the visit is free, and a subtree whose box starts
-// beyond the closest hit so far cannot change the answer (same pruning rule as k_intersect).
+// beyond the closest hit so far cannot change the answer (the exact kernels' pruning rule WITHOUT exact_prune_slack,
+// mirt_dev.h: the ray's reciprocals it needs cost k_shade<VOL> two registers it does not have, 95 -> 97 VGPRs and a
+// wave per SIMD. What that leaves open is a ray that barely moves along an axis and meets a corner of the object's
+// surface to within 1e-6: its inside-object answer may differ from the reference's, inside the image tolerance).
 __device__ inline float trace_object(const DevScene& sc, const VolRoot& R, f3 o, f3 d, int& slot_out) {
     int best_slot = -1;
     float best = -1.f, thr = __builtin_inff();
