@@ -1,13 +1,37 @@
 """One-off differential fuzz campaign on the GPU box (not part of the test suite): many random triangle soups of
 random size, scale and position against the CPU oracle, closest hit in the three modes + visibility.
 usage: python scripts/fuzz_campaign.py first_seed n_seeds [rays]   (prints one line per seed, details of differing rays;
-SEEDS=a,b,c in the environment replaces the range)"""
+SEEDS=a,b,c in the environment replaces the range, AXIS=1 adds near-axis-parallel rays,
+MESH=1 takes closed meshes inside Cornell walls (renderer_amd/meshgen.py) instead of soups)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import renderer_amd as ra, orc
 import test_gpu_fuzz as F
+
+def axis_rays(rng, v, o, d, scale):
+    """AXIS=1: half of the rays replaced by rays that barely move along one or two axes (direction components of
+    1e-8 .. 1e-2) and pass through a corner, an edge midpoint or an interior point of a triangle"""
+    n = o.shape[1]
+    sel = np.nonzero(rng.random(n) < 0.5)[0]
+    m = len(sel)
+    k = rng.integers(0, len(v), m)
+    w = rng.dirichlet((1, 1, 1), m)
+    pick = rng.integers(0, 4, m)
+    w[pick == 0] = (1, 0, 0)
+    w[pick == 1] = (0.5, 0.5, 0)
+    target = (v[k].astype(np.float64) * w[:, :, None]).sum(1)
+    dd = rng.normal(size=(m, 3))
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    small = rng.random((m, 3)) < 0.45
+    small[small.all(1), 0] = False  # (at most two small components)
+    dd = np.where(small, dd * 10.0 ** rng.uniform(-8, -2, (m, 3)), dd)
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    dist = rng.uniform(0.05, 3.0, (m, 1)) * scale
+    o[:, sel] = (target - dd * dist).T.astype(np.float32)
+    d[:, sel] = dd.T.astype(np.float32)
+
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
@@ -21,11 +45,21 @@ for seed in seeds:
     scale = float(10 ** rng.uniform(-3, 3))
     offset = tuple((rng.uniform(-1, 1, 3) * scale * 10 ** rng.uniform(-1, 1.5)).tolist()) if rng.random() < 0.6 else (0.0, 0.0, 0.0)
     n_obj = int(rng.integers(1, 7)) if n_tri >= 40 else 1
-    scene, v = F._soup(ra, rng, n_tri, n_obj, scale, offset)
+    if os.environ.get("MESH"):  # closed, smooth-shaded meshes inside walls instead of a soup: shared edges and corners
+        import renderer_amd.meshgen as meshgen
+        level = int(rng.integers(1, 6))
+        m = meshgen.cornell_with_meshes(level, seed, smooth=bool(rng.integers(0, 2)))
+        m["verts"] = (m["verts"].astype(np.float64) * scale + np.asarray(offset)).astype(np.float32)
+        scene = ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"], m["objects"], m["tri_vn"])
+        v = m["verts"][m["tris"].astype(np.int64)]
+        n_tri, n_obj = len(v), len(m["objects"])
+    else:
+        scene, v = F._soup(ra, rng, n_tri, n_obj, scale, offset)
     tri_obj = scene.raw()["tri_obj"]
     S = orc.OracleScene(scene.raw())
     dev.upload(scene.describe())
     o, d, aux, last = F._rays(rng, v, n, n_obj, ra, scale, offset, tri_obj)
+    if os.environ.get("AXIS"): axis_rays(rng, v, o, d, scale)
     line = "seed %d tris %d scale %.3g offset (%.3g %.3g %.3g):" % ((seed, n_tri, scale) + offset)
     for mode, a in ((0, None), (1, last), (2, aux)):
         tg, ig = dev.intersect(o, d, a, mode)
