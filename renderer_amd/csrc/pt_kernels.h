@@ -832,16 +832,25 @@ k_shade(DevScene sc, DevCamera cam, PathBuf in, const uint32_t* __restrict__ n_i
                 sr.emitted = false;
                 sr.random = true;  // SceneVPMObject.cpp:7; DEFINITE at the medium's boundary (:44, 73, 81, 171, 200, 209)
                 sr.nn = nn;
-                if (go_in) {
+                // The surface met inside this medium is ANOTHER medium's boundary (nested or overlapping media):
+                // SceneVPMObject.cpp:215-228 hands the ray, now at the hit point with intersectDist 0, to
+                // intersectObject->scatter(), which is SceneVPMObject::scatter of the object that was hit: it draws its
+                // own free-flight distance (:8-9, unused) and finds intersectObject == this, insideObject != this,
+                // i.e. "go in" (:16-86) from the medium the path is in; the caller then multiplies originProb by its
+                // own P_surface (:227).
+                const bool other_medium = be_in && out_of_vol && hobj != sobj && ob.type == MIRT_OBJ_VPM;
+                if (go_in || other_medium) {
+                    if (other_medium) (void)rng_float(key, ctr);
                     sr.random = false;
                     const float cur_n = inside >= 0 ? refr_coeff(sc.objects[inside]) : 1.f;
                     float factor;
                     bool through, total;
-                    fresnel_split(nn, d, cur_n, refr_coeff(vo), false, true, false, key, ctr, sr.nd, factor,
+                    fresnel_split(nn, d, cur_n, refr_coeff(ob), false, true, false, key, ctr, sr.nd, factor,
                                   sr.dirProb, through, total);
                     sr.color = total ? mk3(1, 1, 1) : mk3(factor, factor, factor);  // cosine term is 1
-                    sr.contact = sobj;
-                    if (through) sr.inside = sobj;
+                    sr.contact = hobj;
+                    if (through) sr.inside = hobj;
+                    if (other_medium) sr.originProb = vpm_p_surface(vo, t);
                 } else if (be_in && !out_of_vol) {
                     Frame lf = frame_from_normal(d);
                     sr.pos = o + d * samp;

@@ -1,0 +1,94 @@
+"""One-off: path-traced images of random scenes with homogeneous media, GPU against the CPU oracle at the same seed
+(not part of the test suite). A scene: an emissive quad, optionally an outer fog cube or a floor, and 1 .. 5 closed
+objects (cubes of 12 triangles: the small-object shortcut of findInsideObject; displaced icospheres of 80 / 320: the
+object-tree walk) that are media (random sigma_s, sigma_a, g, IOR 1 or 1.1 .. 1.5), glass, mirrors-by-glossy or diffuse, at
+random places, overlapping or nested as they fall; the camera outside or inside. Both integrators.
+usage: fuzz_media.py first_seed n_seeds [spp]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import renderer_amd as ra, orc
+from renderer_amd import meshgen
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((np.clip(a, 0, 1) - np.clip(b, 0, 1)) ** 2)))
+
+
+def medium(rng, ior=None):
+    ob = meshgen._obj(ra.OBJ_VPM, has_vn=0, ior=float(ior if ior is not None else (1.0 if rng.random() < 0.5 else rng.uniform(1.1, 1.5))))
+    ob["sigma_s"] = 10.0 ** rng.uniform(-1.5, 0.8, 3) if rng.random() < 0.8 else (0, 0, 0)
+    ob["sigma_a"] = 10.0 ** rng.uniform(-2.5, 0.0, 3)
+    ob["g"] = float(rng.choice([0.0, rng.uniform(-0.8, 0.9)]))
+    ob["volumetric"] = 1
+    return ob
+
+
+def build(rng):
+    parts = []
+    lz = float(rng.uniform(-1.2, -0.6))
+    lv, lf, _ = meshgen._quad((-0.3, -0.3, lz), (0.3, -0.3, lz), (0.3, 0.3, lz), (-0.3, 0.3, lz), (0, 0, 1))
+    parts.append((lv, lf, meshgen._obj(ra.OBJ_EMISSIVE, (40, 40, 40), has_vn=0)))
+    outer = rng.random()
+    if outer < 0.5:
+        bv, bf = meshgen._box(1.5)
+        parts.append((bv, bf, medium(rng)))
+    elif outer < 0.8:
+        fv, ff, _ = meshgen._quad((-1.4, -0.9, -1.4), (1.4, -0.9, -1.4), (1.4, -0.9, 1.4), (-1.4, -0.9, 1.4), (0, 1, 0))
+        parts.append((fv, ff, meshgen._obj(ra.OBJ_DIFFUSE, (0.7, 0.6, 0.5), has_vn=0)))
+    for k in range(int(rng.integers(1, 6))):
+        c = rng.uniform(-0.8, 0.8, 3)
+        if rng.random() < 0.5:
+            v, f = meshgen._box(float(rng.uniform(0.15, 0.7)), tuple(c))
+        else:
+            v, f = meshgen.displaced_sphere(int(rng.integers(1, 3)), int(rng.integers(0, 1000)), float(rng.uniform(0.15, 0.6)), c,
+                                            amp=float(rng.choice([0.0, 0.12])))
+        u = rng.random()
+        if u < 0.5:
+            ob = medium(rng)
+        elif u < 0.7:
+            ob = meshgen._obj(ra.OBJ_REFRACTIVE, (1, 1, 1), ior=float(rng.uniform(1.2, 1.7)), has_vn=0)
+        elif u < 0.85:
+            ob = meshgen._obj(ra.OBJ_GLOSSY, tuple(rng.uniform(0.5, 0.9, 3)), coeff=float(rng.uniform(3, 60)), has_vn=0)
+        else:
+            ob = meshgen._obj(ra.OBJ_DIFFUSE, tuple(rng.uniform(0.3, 0.9, 3)), has_vn=0)
+        parts.append((v, f, ob))
+    verts, tris, tri_obj, objects, off = [], [], [], [], 0
+    for oi, (pv, pf, ob) in enumerate(parts):
+        verts.append(pv); tris.append(pf + off); tri_obj.append(np.full(len(pf), oi, np.int32)); objects.append(ob); off += len(pv)
+    return ra.HostScene.from_arrays(np.concatenate(verts).astype(np.float32), np.concatenate(tris).astype(np.uint32),
+                                    np.concatenate(tri_obj), np.array(objects, ra.OBJECT_DTYPE), None), [int(o["type"]) for o in objects]
+
+
+dev = ra.Device(device=0)
+spp = int(sys.argv[3]) if len(sys.argv) > 3 else 24
+worst = 0.0
+for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
+    rng = np.random.default_rng(seed)
+    scene, kinds = build(rng)
+    S = orc.OracleScene(scene.raw())
+    dev.upload(scene.describe())
+    if rng.random() < 0.35:
+        pos = tuple(rng.uniform(-1.0, 1.0, 3).tolist())
+    else:
+        w = rng.normal(size=3); w /= np.linalg.norm(w)
+        pos = tuple((w * 3.2).tolist())
+    cam = ra.make_camera(64, 64, 45, position=pos, focus=tuple(rng.uniform(-0.3, 0.3, 3).tolist()))
+    for integ in ("pt", "pttest"):
+        if integ == "pt":
+            g, st = dev.render_pt(cam, spp, seed=3)
+            c, nr = S.render(cam, spp, seed=3, threads=16)
+            c2, _ = S.render(cam, spp, seed=103, threads=16)
+        else:
+            g, st = dev.render_pttest(cam, spp, seed=3)
+            c, nr = S.render_pttest(cam, spp, seed=3, threads=16)[:2]
+            c2 = S.render_pttest(cam, spp, seed=103, threads=16)[0]
+        same, noise = rmse(g / spp, c / spp), rmse(c / spp, c2 / spp)
+        ratio = same / max(noise, 1e-30)
+        worst = max(worst, ratio if noise > 1e-6 else 0.0)
+        print("seed %d kinds %s tris %d cam %s %s: same-seed rmse %.3g noise %.3g ratio %.3g | identical pixels %.3f | nan gpu %d cpu %d | rays gpu %d cpu %d | mean %.5f vs %.5f" % (
+            seed, "".join(str(k) for k in kinds), scene.n_tris, "in " if max(abs(p) for p in pos) <= 1.0 else "out", integ, same, noise, ratio,
+            (g == c).all(-1).mean(), int(np.isnan(g).sum()), int(np.isnan(c).sum()), int(st.n_rays), nr, float(np.nanmean(g / spp)), float(np.nanmean(c / spp))), flush=True)
+    S.close(); scene.close()
+print("worst same-seed / noise ratio %.3g" % worst)

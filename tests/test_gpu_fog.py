@@ -87,6 +87,60 @@ def test_anisotropic_medium_and_camera_outside(gpu, ra, orc):
     s.close()
 
 
+def _medium(ra, ss, sa, ior=1.0, g=0.0):
+    ob = meshgen._obj(ra.OBJ_VPM, has_vn=0, ior=ior)
+    ob["sigma_s"] = (ss,) * 3
+    ob["sigma_a"] = (sa,) * 3
+    ob["g"] = g
+    ob["volumetric"] = 1
+    return ob
+
+
+def _media_scene(ra, parts):
+    lv, lf, _ = meshgen._quad((-0.3, -0.3, -1), (0.3, -0.3, -1), (0.3, 0.3, -1), (-0.3, 0.3, -1), (0, 0, 1))
+    parts = [(lv, lf, meshgen._obj(ra.OBJ_EMISSIVE, (40, 40, 40), has_vn=0))] + parts
+    verts, tris, tri_obj, objects, off = [], [], [], [], 0
+    for oi, (pv, pf, ob) in enumerate(parts):
+        verts.append(pv)
+        tris.append(pf + off)
+        tri_obj.append(np.full(len(pf), oi, np.int32))
+        objects.append(ob)
+        off += len(pv)
+    return ra.HostScene.from_arrays(np.concatenate(verts).astype(np.float32), np.concatenate(tris).astype(np.uint32),
+                                    np.concatenate(tri_obj), np.array(objects, ra.OBJECT_DTYPE), None)
+
+
+@pytest.mark.parametrize("case", ["nested", "nested_ior", "nested_outer_clear", "overlapping", "glass_in_fog_in_fog"])
+def test_nested_and_overlapping_media(gpu, ra, orc, case):
+    """A path inside one medium that reaches ANOTHER medium's boundary before it scatters: SceneVPMObject.cpp:215-228
+    hands it to the hit object's scatter(), which for a medium is "go in" (:16-86) after a free-flight draw of its own.
+    Found by scripts/fuzz_media.py: the device had no such case and ended those paths (an outer medium that does not
+    scatter rendered black behind an inner one). Ray counts equal to the oracle's to the ray, images as in _parity."""
+    box = meshgen._box
+    parts = {
+        "nested": [box(1.5) + (_medium(ra, 0.5, 0.1),), box(0.4, (0.2, 0.1, 0.0)) + (_medium(ra, 2.0, 0.2),)],
+        "nested_ior": [box(1.5) + (_medium(ra, 0.5, 0.1, ior=1.2),), box(0.4, (0.2, 0.1, 0.0)) + (_medium(ra, 2.0, 0.2, ior=1.4, g=0.5),)],
+        "nested_outer_clear": [box(1.5) + (_medium(ra, 0.0, 0.1),), box(0.4, (0.2, 0.1, 0.0)) + (_medium(ra, 2.0, 0.2),)],
+        "overlapping": [box(0.5, (-0.2, 0, 0)) + (_medium(ra, 1.0, 0.1),), box(0.5, (0.3, 0.1, 0.0)) + (_medium(ra, 2.0, 0.2, ior=1.3),)],
+        "glass_in_fog_in_fog": [box(1.5) + (_medium(ra, 0.3, 0.05),), box(0.6, (0.1, 0.0, 0.0)) + (_medium(ra, 1.0, 0.1, ior=1.2),),
+                                box(0.25, (0.1, 0.1, 0.0)) + (meshgen._obj(ra.OBJ_REFRACTIVE, (1, 1, 1), ior=1.5, has_vn=0),)],
+    }[case]
+    s = _media_scene(ra, parts)
+    S = orc.OracleScene(s.raw())
+    gpu.upload(s.describe())
+    cam = ra.make_camera(64, 64, 45, position=(0.4, 0.3, 3.2), focus=(0, 0, 0))
+    g, st = gpu.render_pt(cam, 16, seed=3)
+    c, nr = S.render(cam, 16, seed=3, threads=16)
+    assert abs(int(st.n_rays) - nr) <= 1e-3 * nr, (int(st.n_rays), nr)
+    assert (g == c).all(-1).mean() > 0.95
+    assert c.mean() > 0 and abs(g.mean() - c.mean()) <= 0.02 * c.mean(), (g.mean(), c.mean())
+    gt, _ = gpu.render_pttest(cam, 16, seed=3)
+    ct = S.render_pttest(cam, 16, seed=3, threads=16)[0]
+    assert ct.mean() > 0 and abs(gt.mean() - ct.mean()) <= 0.02 * ct.mean(), (gt.mean(), ct.mean())
+    S.close()
+    s.close()
+
+
 def test_render_refuses_medium_without_its_tree(gpu, ra):
     s = meshgen.fog_box_scene((0.3, 0.3, 0.3), (0.2, 0.2, 0.2))
     d = s.describe()
