@@ -3,13 +3,16 @@
 objects (cubes of 12 triangles: the small-object shortcut of findInsideObject; displaced icospheres of 80 / 320: the
 object-tree walk) that are media (random sigma_s, sigma_a, g, IOR 1 or 1.1 .. 1.5), glass, mirrors-by-glossy or diffuse, at
 random places, overlapping or nested as they fall; the camera outside or inside. Both integrators.
-usage: fuzz_media.py first_seed n_seeds [spp]"""
+usage: [RICH=1] fuzz_media.py first_seed n_seeds [spp]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import renderer_amd as ra, orc
 from renderer_amd import meshgen
+
+
+RICH = int(os.environ.get("RICH", "0"))  # RICH=1: smooth normals, mirrors, Phong objects, more emitters, 1 280-triangle balls
 
 
 def rmse(a, b):
@@ -39,26 +42,34 @@ def build(rng):
         parts.append((fv, ff, meshgen._obj(ra.OBJ_DIFFUSE, (0.7, 0.6, 0.5), has_vn=0)))
     for k in range(int(rng.integers(1, 6))):
         c = rng.uniform(-0.8, 0.8, 3)
+        smooth = 0
         if rng.random() < 0.5:
             v, f = meshgen._box(float(rng.uniform(0.15, 0.7)), tuple(c))
         else:
-            v, f = meshgen.displaced_sphere(int(rng.integers(1, 3)), int(rng.integers(0, 1000)), float(rng.uniform(0.15, 0.6)), c,
+            v, f = meshgen.displaced_sphere(int(rng.integers(1, 3 + RICH)), int(rng.integers(0, 1000)), float(rng.uniform(0.15, 0.6)), c,
                                             amp=float(rng.choice([0.0, 0.12])))
+            smooth = int(rng.integers(0, 2)) if RICH else 0  # interpolated vertex normals (also on a medium's boundary)
         u = rng.random()
         if u < 0.5:
             ob = medium(rng)
         elif u < 0.7:
-            ob = meshgen._obj(ra.OBJ_REFRACTIVE, (1, 1, 1), ior=float(rng.uniform(1.2, 1.7)), has_vn=0)
+            ob = meshgen._obj(ra.OBJ_REFRACTIVE, (1, 1, 1), ior=float(rng.uniform(1.2, 1.7)) if not RICH or rng.random() < 0.7 else -1.0)
         elif u < 0.85:
-            ob = meshgen._obj(ra.OBJ_GLOSSY, tuple(rng.uniform(0.5, 0.9, 3)), coeff=float(rng.uniform(3, 60)), has_vn=0)
+            ob = meshgen._obj(ra.OBJ_GLOSSY if not RICH or rng.random() < 0.6 else ra.OBJ_PHONG, tuple(rng.uniform(0.5, 0.9, 3)),
+                              coeff=float(rng.uniform(3, 60)), color2=tuple(rng.uniform(0.1, 0.5, 3)))
+        elif RICH and u < 0.9:
+            ob = meshgen._obj(ra.OBJ_EMISSIVE, tuple(rng.uniform(2, 10, 3)))
         else:
-            ob = meshgen._obj(ra.OBJ_DIFFUSE, tuple(rng.uniform(0.3, 0.9, 3)), has_vn=0)
+            ob = meshgen._obj(ra.OBJ_DIFFUSE, tuple(rng.uniform(0.3, 0.9, 3)))
+        ob["has_vn"] = smooth
         parts.append((v, f, ob))
-    verts, tris, tri_obj, objects, off = [], [], [], [], 0
+    verts, tris, tri_obj, objects, vns, off = [], [], [], [], [], 0
     for oi, (pv, pf, ob) in enumerate(parts):
         verts.append(pv); tris.append(pf + off); tri_obj.append(np.full(len(pf), oi, np.int32)); objects.append(ob); off += len(pv)
+        vns.append(meshgen.vertex_normals(np.asarray(pv, np.float64), np.asarray(pf, np.int64))[pf].reshape(len(pf), 9))
     return ra.HostScene.from_arrays(np.concatenate(verts).astype(np.float32), np.concatenate(tris).astype(np.uint32),
-                                    np.concatenate(tri_obj), np.array(objects, ra.OBJECT_DTYPE), None), [int(o["type"]) for o in objects]
+                                    np.concatenate(tri_obj), np.array(objects, ra.OBJECT_DTYPE),
+                                    np.concatenate(vns).astype(np.float32)), [int(o["type"]) for o in objects]
 
 
 dev = ra.Device(device=0)
