@@ -1,5 +1,5 @@
 """One-off: path-traced images of random triangle soups (slivers, degenerate and duplicated triangles, random vertex
-normals; one emissive object), GPU against the CPU oracle at the same seed. usage: fuzz_pt.py first_seed n_seeds"""
+normals; one emissive object), GPU against the CPU oracle at the same seed. usage: [TEX=1|2] fuzz_pt.py first_seed n_seeds   (TEX=1: random textures on the materials, TEX=2: bump maps too)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -18,7 +18,11 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     n_obj = 6
     scale = float(10 ** rng.uniform(-2, 2.5)) if seed % 2 else 1.0
     offset = tuple((rng.uniform(-1, 1, 3) * scale * 8).tolist()) if seed % 4 == 3 else (0.0, 0.0, 0.0)
-    scene, v = F._soup(ra, rng, n_tri, n_obj, scale, offset)
+    try:
+        scene, v = F._soup(ra, rng, n_tri, n_obj, scale, offset)
+    except ra.MirtError as e:  # (a small soup can leave an object without triangles: the loader refuses it)
+        print("seed %d skipped: %s" % (seed, e), flush=True)
+        continue
     raw = scene.raw()
     objs = raw["objects"].copy()
     kinds = [ra.OBJ_EMISSIVE, ra.OBJ_DIFFUSE, ra.OBJ_GLOSSY, ra.OBJ_REFRACTIVE, ra.OBJ_PHONG, ra.OBJ_DIFFUSE]
@@ -28,6 +32,25 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
         objs[k] = np.array(o, ra.OBJECT_DTYPE)
     scene.close()
     scene = ra.HostScene.from_arrays(raw["verts"], raw["tris"], raw["tri_obj"], objs, raw["tri_vn"])
+    if os.environ.get("TEX"):  # random textures (rgb / gray, 1 .. 16 texels a side, random transforms) on random materials, bump maps too
+        texs = []
+        for k in range(int(rng.integers(1, 5))):
+            h, w = int(rng.integers(1, 17)), int(rng.integers(1, 17))
+            tx = rng.uniform(0.05, 0.95, (h, w, 3) if rng.random() < 0.6 else (h, w)).astype(np.float32)
+            coord = np.eye(4, dtype=np.float32); color = np.eye(4, dtype=np.float32)
+            if rng.random() < 0.5:
+                coord[0, 0], coord[1, 1] = rng.uniform(0.3, 4, 2); coord[0, 3], coord[1, 3] = rng.uniform(-1, 1, 2)
+            if rng.random() < 0.3:
+                color[0, 0] = color[1, 1] = color[2, 2] = rng.uniform(0.5, 1.0)
+            texs.append(ra.make_texture(tx, coord, color))
+        ot = np.full(n_obj, -1, ra.OBJECT_TEX_DTYPE)
+        for k in range(1, n_obj):
+            for field, pr in (("diffuse", 0.5), ("glossy_color", 0.4), ("glossy_coeff", 0.25), ("bump", 0.25 if os.environ["TEX"] == "2" else 0.0)):
+                if rng.random() < pr:
+                    ot[field][k] = int(rng.integers(0, len(texs)))
+        vt = rng.uniform(-0.5, 1.5, (len(raw["tris"]), 3, 3)).astype(np.float32)
+        vt[..., 2] = 0
+        scene.set_textures(vt.reshape(-1, 9), texs, ot)
     S = orc.OracleScene(scene.raw())
     dev.upload(scene.describe())
     cam = ra.make_camera(96, 96, 60, position=(offset[0], offset[1], offset[2] + 3.2 * scale), focus=offset)
