@@ -12,7 +12,7 @@ import renderer_amd as ra, orc
 from renderer_amd import meshgen
 
 
-RICH = int(os.environ.get("RICH", "0"))  # RICH=1: smooth normals, mirrors, Phong objects, more emitters, 1 280-triangle balls
+RICH = int(os.environ.get("RICH", "0"))  # RICH=1: smooth normals, mirrors, Phong objects, more emitters, 1 280-triangle balls; RICH=2: random image shape, field of view, depth cap, first sample and seed too
 
 
 def rmse(a, b):
@@ -85,16 +85,24 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     else:
         w = rng.normal(size=3); w /= np.linalg.norm(w)
         pos = tuple((w * 3.2).tolist())
-    cam = ra.make_camera(64, 64, 45, position=pos, focus=tuple(rng.uniform(-0.3, 0.3, 3).tolist()))
+    kw = {}
+    if RICH >= 2:  # any image shape and field of view, any depth cap, any first sample, any seed
+        cam = ra.make_camera(int(rng.integers(8, 96)), int(rng.integers(8, 96)), int(rng.integers(15, 121)), position=pos,
+                             focus=tuple(rng.uniform(-0.3, 0.3, 3).tolist()), up=tuple(rng.normal(size=3).tolist()))
+        kw = dict(max_depth=int(rng.integers(1, 21)), spp_begin=int(rng.integers(0, 100)))
+        sd = int(rng.integers(1, 10000))
+    else:
+        cam = ra.make_camera(64, 64, 45, position=pos, focus=tuple(rng.uniform(-0.3, 0.3, 3).tolist()))
+        sd = 3
     for integ in ("pt", "pttest"):
         if integ == "pt":
-            g, st = dev.render_pt(cam, spp, seed=3)
-            c, nr = S.render(cam, spp, seed=3, threads=16)
-            c2, _ = S.render(cam, spp, seed=103, threads=16)
+            g, st = dev.render_pt(cam, spp, seed=sd, **kw)
+            c, nr = S.render(cam, spp, seed=sd, threads=16, **kw)
+            c2, _ = S.render(cam, spp, seed=sd + 100, threads=16, **kw)
         else:
-            g, st = dev.render_pttest(cam, spp, seed=3)
-            c, nr = S.render_pttest(cam, spp, seed=3, threads=16)[:2]
-            c2 = S.render_pttest(cam, spp, seed=103, threads=16)[0]
+            g, st = dev.render_pttest(cam, spp, seed=sd, **kw)
+            c, nr = S.render_pttest(cam, spp, seed=sd, threads=16, **kw)[:2]
+            c2 = S.render_pttest(cam, spp, seed=sd + 100, threads=16, **kw)[0]
         same, noise = rmse(g / spp, c / spp), rmse(c / spp, c2 / spp)
         ratio = same / max(noise, 1e-30)
         worst = max(worst, ratio if noise > 1e-6 else 0.0)
