@@ -2,6 +2,7 @@
 random size, scale and position against the CPU oracle, closest hit in the three modes + visibility.
 usage: python scripts/fuzz_campaign.py first_seed n_seeds [rays]   (prints one line per seed, details of differing rays;
 SEEDS=a,b,c in the environment replaces the range, AXIS=1 adds near-axis-parallel rays,
+VIS1=1 adds the visibility query in mode 1,
 MESH=1 takes closed meshes inside Cornell walls (renderer_amd/meshgen.py) instead of soups)"""
 import os, sys, time
 import numpy as np
@@ -72,7 +73,7 @@ for seed in seeds:
     tc, ic = S.intersect(o, d, aux, 2, threads=16)
     lim = np.where(ic >= 0, tc, scale).astype(np.float32)
     lim = (lim * rng.choice(np.array([0.5, 1.0 - 1e-6, 1.0, 1.0 + 1e-6, 1.0 + 1e-4, 2.0, 100.0], np.float32), n)).astype(np.float32)
-    for mode, a in ((2, aux), (0, None)):
+    for mode, a in ((2, aux), (0, None)) + (((1, last),) if os.environ.get("VIS1") else ()):
         vg = dev.visibility(o, d, a, lim, mode)
         vc = S.visibility(o, d, a, lim, mode, threads=16)
         nd = int((vg != vc).sum())
