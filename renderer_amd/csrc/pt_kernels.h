@@ -648,10 +648,15 @@ __device__ __forceinline__ bool connect_light(const DevScene& sc, const DevObjec
         const f3 gcol = glossy_color(sc, hob, T, slot, pos);
         const float gcoeff = glossy_coeff(sc, hob, T, slot, pos);
         const f3 refl = (nn * (-dot3(nn, d))) * 2.f + d;
+        // (GlossyMaterial.cpp:79 multiplies by max(colour) whatever evaluate() returned: a colour that is NaN - the
+        // texture read at the NaN coordinate of a degenerate triangle - makes the product NaN, not zero, and the
+        // connection goes on with it: scripts/fuzz_pt.py TEX=2, seed 3243)
+        f3 c = mk3(0, 0, 0);
         if (sides) {
             const float rd = dot3(refl, odir);
-            if (rd > 0.f) bsdf = (gcol * powf(rd, gcoeff)) * max3f(gcol);
+            if (rd > 0.f) c = gcol * powf(rd, gcoeff);
         }
+        bsdf = c * max3f(gcol);
         pdf = cos_pdf(refl, odir, gcoeff);  // GlossyMaterial.cpp:58-67
         if (hob.type == MIRT_OBJ_PHONG) {  // SceneObject.cpp:227-248, 341-352: BSDFs add, densities average
             bsdf = (mk3(0, 0, 0) + bsdf) + (sides ? div3(col, 3.14159265358979f) : mk3(0, 0, 0));

@@ -68,4 +68,12 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
         print("seed %d tris %d scale %.3g %s: same-seed rmse %.3g noise %.3g ratio %.3g | identical pixels %.3f | nan gpu %d cpu %d | rays gpu %d cpu %d | mean %s vs %s" % (
             seed, n_tri, scale, integ, same, noise, same / max(noise, 1e-30), (g == c).all(-1).mean(), int(np.isnan(g).sum()), int(np.isnan(c).sum()),
             int(st.n_rays), nr, np.nanmean(g / spp, (0, 1)).round(4), np.nanmean(c / spp, (0, 1)).round(4)), flush=True)
+        if int(np.isnan(g).sum()) != int(np.isnan(c).sum()):  # where does the NaN enter? the pixel at rising depth caps
+            ys, xs = np.nonzero(np.isnan(g).any(-1) != np.isnan(c).any(-1))
+            for depth in range(1, 12):
+                if integ == "pt":
+                    gd = dev.render_pt(cam, spp, seed=3, max_depth=depth)[0]; cd = S.render(cam, spp, seed=3, threads=16, max_depth=depth)[0]
+                else:
+                    gd = dev.render_pttest(cam, spp, seed=3, max_depth=depth)[0]; cd = S.render_pttest(cam, spp, seed=3, threads=16, max_depth=depth)[0]
+                print("   pixel (%d, %d) depth cap %d: gpu %s cpu %s" % (ys[0], xs[0], depth, gd[ys[0], xs[0]], cd[ys[0], xs[0]]), flush=True)
     S.close(); scene.close()
