@@ -795,6 +795,11 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
     for (int c = 0; c < 3; c++)
         for (float v : {s->node_min[c], s->node_max[c]}) bound[c] = std::max(bound[c], std::fabs(v));
     int fast_ok = bounds_in_model(main_tree) ? 1 : 0;
+    // (a NaN corner drops out of the min / max that make the node boxes, so the boxes alone do not show it: a scene with
+    // a corner that is not finite, or beyond the model's 2^60, takes the exact kernels, whose arithmetic on such
+    // values is the reference's; the fast tree's builder is not asked to bin them)
+    for (size_t k = 0; fast_ok && k < 9 * (size_t)T; k++)
+        if (!(std::fabs(s->tri_pos[k]) < 1.1529215e18f)) fast_ok = 0;
     if ((long long)T + extra_slots > (1 << 24))
         return fail(ctx, MIRT_E_LIMIT, "mirt_upload_scene: more than 2^24 triangle slots");
     std::vector<PairRec> pairs;
@@ -898,6 +903,7 @@ int mirt_upload_scene(MirtContext* ctx, const MirtSceneDesc* s) {
                 }
                 rnodes[i].jump[f] = j;
             }
+        if (!fast_ok) use_fast = false;
         if (use_fast) {
             FastTree ft;
             const float bmax = std::max(bound[0], std::max(bound[1], bound[2]));
@@ -1474,6 +1480,14 @@ int mirt_fast_tree(const MirtSceneDesc* s, int32_t capacity_nodes, int32_t* n_no
         return MIRT_E_INVALID;
     }
     if (s->n_tris > 0 && (!s->tri_pos || !s->slot_tid)) return MIRT_E_INVALID;
+    {  // (as mirt_upload_scene: no fast tree for a scene outside the classifier's model)
+        bool in_model = bounds_in_model(view);
+        for (size_t k = 0; in_model && k < 9 * (size_t)s->n_tris; k++) in_model = std::fabs(s->tri_pos[k]) < 1.1529215e18f;
+        if (!in_model) {
+            g_create_err = "mirt_fast_tree: coordinates that are not finite or beyond 2^60: such a scene has no fast tree";
+            return MIRT_E_INVALID;
+        }
+    }
     FastTree ft;
     const std::vector<int> src = seam_order(view);  // device slot -> position in the reference's slot order
     float bmax = 0.f;

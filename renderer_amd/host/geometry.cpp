@@ -358,6 +358,14 @@ void KDTree::build(Strategy strategy) {
         for (int k = 0; k < 3; k++)
             if (t.vertexIndices[k] >= vertexPositionList.size())
                 throw std::runtime_error("KDTree::build: vertex index out of range");
+    // The build orders vertex coordinates (std::nth_element / sort in the reference, KDTree.cpp:54-127, 160-196): with a
+    // NaN among them the ordering is not one, and what the reference builds depends on its library. Refused.
+    for (auto& t : triangleList)
+        for (int k = 0; k < 3; k++) {
+            const vec3f& p = vertexPositionList[t.vertexIndices[k]];
+            if (p.x != p.x || p.y != p.y || p.z != p.z)
+                throw std::runtime_error("KDTree::build: a triangle corner has a NaN coordinate");
+        }
     std::vector<unsigned> order(triangleList.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = (unsigned)i;
     std::vector<unsigned> stamp(vertexPositionList.size(), 0), uniq;

@@ -314,3 +314,31 @@ def test_special_value_rays(gpu, ra, orc, seed, n_tri):
             assert len(diff) == 0, (mode, len(diff), [(int(q), int(vg[q]), int(vc[q]), float(lim[q]), o[:, q].tolist(), d[:, q].tolist()) for q in diff[:4]])
     S.close()
     scene.close()
+
+
+@pytest.mark.parametrize("value", [np.inf, -np.inf, 3e38, 1e20, 1e-42])
+def test_special_value_scene(gpu, ra, orc, value):
+    """A scene with corners at +-inf, near FLT_MAX, 1e20 or denormal: it leaves the classifier's error model, so upload
+    builds no fast tree (its builder would bin by those values: a host crash before this test existed) and every query
+    takes the exact kernels, whose arithmetic on such values is the reference's. (NaN corners are refused by the host
+    surface, tests/test_host.py: the reference's tree build is undefined for them.)"""
+    rng = np.random.default_rng(1)
+    scene, v = _soup(ra, rng, 300, 3)
+    raw = scene.raw()
+    verts = raw["verts"].copy()
+    verts[7, 1] = value
+    verts[100, 0] = value
+    s2 = ra.HostScene.from_arrays(verts, raw["tris"], raw["tri_obj"], raw["objects"], raw["tri_vn"])
+    gpu.upload(s2.describe())
+    S = orc.OracleScene(s2.raw())
+    o, d, aux, last = _rays(rng, v, 50000, 3, ra, tri_obj=raw["tri_obj"])
+    with np.errstate(all="ignore"):
+        for mode, a in ((0, None), (1, last), (2, aux)):
+            tg, ig = gpu.intersect(o, d, a, mode)
+            tc, ic = S.intersect(o, d, a, mode, threads=16)
+            assert np.array_equal(ig, ic) and np.array_equal(tg, tc, equal_nan=True), mode
+        img, st = gpu.render_pt(ra.make_camera(32, 32, 30, position=(0, 0, 3.2)), 4, seed=1)
+        assert int(st.n_rays) > 0
+    S.close()
+    s2.close()
+    scene.close()

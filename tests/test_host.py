@@ -364,3 +364,15 @@ def test_phong_material_from_xml(ra, tmp_path):
     (tmp_path / "s.xml").write_text((tmp_path / "s.xml").read_text().replace("<DiffuseComponent>", "<X>").replace("</DiffuseComponent>", "</X>"))
     with pytest.raises(ra.MirtError, match="GlossyComponent"):
         ra.HostScene.load_config(str(tmp_path / "c.xml"))
+
+
+def test_nan_corner_is_refused(ra):
+    """The reference's tree build orders vertex coordinates; with a NaN among them there is no order and no defined
+    answer. The host surface says so instead of building something."""
+    m = meshgen.cornell_with_meshes(1)
+    verts = m["verts"].copy()
+    verts[int(m["tris"][5][1]), 2] = np.nan
+    with pytest.raises(ra.MirtError, match="NaN"):
+        ra.HostScene.from_arrays(verts, m["tris"], m["tri_obj"], m["objects"], m["tri_vn"])
+    verts[int(m["tris"][5][1]), 2] = np.inf  # infinities order fine
+    ra.HostScene.from_arrays(verts, m["tris"], m["tri_obj"], m["objects"], m["tri_vn"]).close()
