@@ -3,7 +3,7 @@
 objects (cubes of 12 triangles: the small-object shortcut of findInsideObject; displaced icospheres of 80 / 320: the
 object-tree walk) that are media (random sigma_s, sigma_a, g, IOR 1 or 1.1 .. 1.5), glass, mirrors-by-glossy or diffuse, at
 random places, overlapping or nested as they fall; the camera outside or inside. Both integrators.
-usage: [RICH=1] fuzz_media.py first_seed n_seeds [spp]"""
+usage: [RICH=1|2] [EXTREME=1] fuzz_media.py first_seed n_seeds [spp]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -62,6 +62,15 @@ def build(rng):
         else:
             ob = meshgen._obj(ra.OBJ_DIFFUSE, tuple(rng.uniform(0.3, 0.9, 3)))
         ob["has_vn"] = smooth
+        if os.environ.get("EXTREME") and rng.random() < 0.7:  # parameters at and beyond the edges of what makes sense
+            pick = lambda vals: float(vals[int(rng.integers(0, len(vals)))])
+            which = int(rng.integers(0, 6))
+            if which == 0: ob["ior"] = pick([0.0, 1e-3, 1.0, 50.0, 1e6] if int(ob["type"]) != ra.OBJ_REFRACTIVE else [0.0, 1e-3, 1.0, 50.0, 1e6, -1.0])
+            elif which == 1: ob["g"] = pick([-1.0, 1.0, 0.999, -0.999, 1e-6, 2.0])
+            elif which == 2: ob["sigma_s"] = (pick([0.0, 1e-8, 1e4]),) * 3; ob["sigma_a"] = (pick([0.0, 1e-8, 1e4]),) * 3
+            elif which == 3: ob["coeff"] = pick([0.0, -1.0, -0.5, 1e4, 1e-3])
+            elif which == 4: ob["color"] = (pick([0.0, 1.0, 2.0, -0.5, 1e-4]), pick([0.0, 1.0, 2.0]), pick([0.0, 1.0, 1e3]))
+            else: ob["decay"] = (pick([0.0, 1.0, 2.0, 0.5]),) * 3
         parts.append((v, f, ob))
     verts, tris, tri_obj, objects, vns, off = [], [], [], [], [], 0
     for oi, (pv, pf, ob) in enumerate(parts):
