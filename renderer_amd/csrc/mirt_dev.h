@@ -614,13 +614,21 @@ __device__ __forceinline__ f3 apply_rows(const float* m, f3 v) {
     return mk3(((v.x * m[0] + v.y * m[1]) + v.z * m[2]) + m[3], ((v.x * m[4] + v.y * m[5]) + v.z * m[6]) + m[7],
                ((v.x * m[8] + v.y * m[9]) + v.z * m[10]) + m[11]);
 }
+// (int)floor(x) as the reference's platform computes it: x86's cvttss2si / cvttsd2si return INT_MIN for a NaN and for
+// anything outside of int's range, where this GPU's conversion saturates and turns a NaN into 0. A texture coordinate IS
+// NaN, or astronomically large, on a degenerate or needle triangle (getTexCoord divides by ~0), and the texel the
+// reference then reads decides a bump-mapped normal (scripts/fuzz_pt.py TEX=2, seed 7132).
+__device__ __forceinline__ int floor_to_int_x86(float x) {
+    const float f = floorf(x);
+    return (f >= -2147483648.f && f < 2147483648.f) ? (int)f : (int)0x80000000;
+}
 // Texture::getColor: bilinear, wrapping, texel centres at +0.5; the gray branch reads its fourth texel
 // at (top, LEFT) as the reference does (Texture.cpp:86)
 __device__ __forceinline__ f3 tex_color(const DevTexture& X, f3 coord) {
     const f3 tc = apply_rows(X.coord, coord);
     float u = tc.x * (float)X.width - 0.5f;
     float v = tc.y * (float)X.height - 0.5f;
-    int left = (int)floorf(u), bottom = (int)floorf(v);
+    int left = floor_to_int_x86(u), bottom = floor_to_int_x86(v);
     int right = left + 1, top = bottom + 1;
     u -= (float)left;
     v -= (float)bottom;
@@ -665,7 +673,7 @@ __device__ __forceinline__ f3 tex_grad(const DevTexture& X, const float* inv, f3
     const f3 tc = apply_rows(X.coord, coord);
     const float u = tc.x * (float)X.width - 0.5f;
     const float v = tc.y * (float)X.height - 0.5f;
-    int left = (int)floorf(u), bottom = (int)floorf(v);
+    int left = floor_to_int_x86(u), bottom = floor_to_int_x86(v);
     int right = left + 1, top = bottom + 1;
     left %= X.width;
     right %= X.width;
