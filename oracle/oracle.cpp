@@ -1042,7 +1042,7 @@ struct Tracer {
         }
         float dx = rng.genFloat(), dy = rng.genFloat();
         out.direction = lf.toWorld(hemiCos(1.f, dx, dy));
-        float p = std::max(color.x, std::max(color.y, color.z));
+        float p = maxComp(color);
         if (rng.genFloat() < p) {
             // DiffuseBSDF.h:18-24
             if (dot(lf.n, in.direction) <= 0 && dot(lf.n, out.direction) >= 0)
@@ -1087,7 +1087,7 @@ struct Tracer {
             if (dot(r2, out.direction) > 0) out.color = color * powf(dot(r2, out.direction), coeff);
         }
         out.directionProb = cosPdf(out_lf, out.direction, coeff);
-        float p = std::max(color.x, std::max(color.y, color.z));
+        float p = maxComp(color);
         if (length(out.color) == 0) {
             out.direction = V3(0, 0, 0);
             out.color = V3(0, 0, 0);
@@ -1107,6 +1107,14 @@ struct Tracer {
     // smallFuncs.h:11-24 applied to a direction (w = 0)
     static V3 rotate(const V3& axis, float angle, const V3& v) { return rotateDir(axis, angle, v); }
     static float clampf(float v, float lo, float hi) { return v < lo ? lo : v > hi ? hi : v; }
+    // *std::max_element(&c.x, &c.x + 3) (DiffuseMaterial.cpp:48,84,91, GlossyMaterial.cpp:30,75,84): the first component
+    // stays the largest unless a later one compares greater, which is what decides the result for a NaN component
+    static float maxComp(const V3& c) {
+        float m = c.x;
+        if (m < c.y) m = c.y;
+        if (m < c.z) m = c.z;
+        return m;
+    }
 
     // RefractiveMaterial.cpp:4-104
     PRay scatterRefractive(int object, const PRay& in, Stream& rng) const {
@@ -1684,7 +1692,7 @@ struct Tracer {
             return V3(0, 0, 0);
         }
         auto glossy = [&](const V3& gc) {
-            float p = std::max(gc.x, std::max(gc.y, gc.z));
+            float p = maxComp(gc);
             V3 c(0, 0, 0);
             if (dot(lf.n, inRay.direction) <= 0 && dot(lf.n, outRay.direction) >= 0) {
                 V3 r2 = -dot(lf.n, inRay.direction) * lf.n * 2 + inRay.direction;
@@ -1727,7 +1735,7 @@ struct Tracer {
         if (o.type == ORC_DIFFUSE) {
             LocalFrame lf;
             lf.buildFromNormal(objNormal(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin));
-            float p = std::max(dcolor.x, std::max(dcolor.y, dcolor.z));
+            float p = maxComp(dcolor);
             return p * cosPdf(lf, outRay.direction, 1.f);
         }
         if (o.type == ORC_GLOSSY) {
@@ -1750,7 +1758,7 @@ struct Tracer {
             {
                 LocalFrame lf;
                 lf.buildFromNormal(objNormal(outRay.contactObject, outRay.contactObjectTriangleID, outRay.origin));
-                float p = std::max(dcolor.x, std::max(dcolor.y, dcolor.z));
+                float p = maxComp(dcolor);
                 prob += p * cosPdf(lf, outRay.direction, 1.f);
             }
             return prob / 2;

@@ -209,7 +209,14 @@ __device__ __forceinline__ float cos_pdf(f3 n, f3 dir, float coeff) {
     c = c > 0.f ? c : 0.f;
     return (float)((double)(powf(c, coeff) * (coeff + 1.f)) / 6.28318530717958);
 }
-__device__ __forceinline__ float max3f(f3 c) { return fmaxf(c.x, fmaxf(c.y, c.z)); }
+// *std::max_element(&c.x, &c.x + 3) (DiffuseMaterial.cpp:48,84,91, GlossyMaterial.cpp:30,75,84): the first component stays
+// the largest unless a later one compares greater (fmaxf would drop a NaN component where this keeps or skips it)
+__device__ __forceinline__ float max3f(f3 c) {
+    float m = c.x;
+    if (m < c.y) m = c.y;
+    if (m < c.z) m = c.z;
+    return m;
+}
 __device__ __forceinline__ float clampf(float v, float lo, float hi) {
     return v < lo ? lo : (v > hi ? hi : v);
 }
