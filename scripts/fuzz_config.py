@@ -4,7 +4,8 @@ guillotine partition into tiles, random samples-per-launch, both integrators:
   (a) tiles rendered one by one and put side by side == the full frame, bit for bit, ray and sample counts equal;
   (b) the full frame with a random samples-per-launch (chained wavefronts) == the default, bit for bit;
   (c) two sample ranges [0, a) + [a, a + b) added == [0, a + b) up to the one float addition per pixel that differs.
-usage: [RICH=1] fuzz_config.py first_seed n_seeds"""
+  (d) MULTI=1: two or three contexts, tiles gathered == the frame bit for bit, sample shards reduced == the frame.
+usage: [RICH=1] [MULTI=1] fuzz_config.py first_seed n_seeds"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,11 +27,13 @@ def partition(rng, x0, y0, w, h, depth):
 
 
 dev = ra.Device(device=0)
+more = [ra.Device(device=0) for _ in range(2)] if os.environ.get("MULTI") else []  # (d): three contexts on this GPU
 bad = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     rng = np.random.default_rng(seed)
     scene, kinds = ns["build"](rng)
     dev.upload(scene.describe())
+    for m in more: m.upload(scene.describe())
     W, H = int(rng.integers(3, 90)), int(rng.integers(3, 90))
     w3 = rng.normal(size=3); w3 /= np.linalg.norm(w3)
     pos = tuple(rng.uniform(-1, 1, 3).tolist()) if rng.random() < 0.35 else tuple((w3 * 3.2).tolist())
@@ -61,6 +64,15 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
         line += " %s a %s b(spl %d) %s c(%d+%d) %s |" % ("pttest" if pttest else "pt", "ok" if a_ok else "DIFFER", spl, "ok" if b_ok else "DIFFER",
                                                        a, spp - a, "ok" if c_ok else "DIFFER")
         bad += (not a_ok) + (not b_ok) + (not c_ok)
+        if more:  # (d) several contexts: tiles gathered == the frame bit for bit; sample shards reduced == the frame to the additions
+            k = int(rng.integers(2, 4))
+            mt, s3 = ra.render_pt_multi([dev] + more[:k - 1], cam, spp, spp_begin=s0, seed=rseed, pttest=pttest, shard=ra.SHARD_TILES)
+            d1 = np.array_equal(mt, full, equal_nan=True) and int(s3.n_rays) == int(st.n_rays)
+            ms, s4 = ra.render_pt_multi([dev] + more[:k - 1], cam, spp, spp_begin=s0, seed=rseed, pttest=pttest)
+            with np.errstate(invalid="ignore"):
+                d2 = np.allclose(ms, full, rtol=2e-5, atol=1e-6 * max(1.0, float(np.nanmax(np.abs(full)))), equal_nan=True) and int(s4.n_rays) == int(st.n_rays)
+            line += " d(%d ctx) %s %s |" % (k, "ok" if d1 else "DIFFER", "ok" if d2 else "DIFFER")
+            bad += (not d1) + (not d2)
     print(line, flush=True)
     scene.close()
 print("config fuzz: %d failed equivalences" % bad)
