@@ -12,6 +12,7 @@ import renderer_amd as ra, orc
 from renderer_amd import meshgen
 
 
+SCALE = [1.0, (0.0, 0.0, 0.0)]  # SCALED=1: the whole scene (and the camera) scaled by 1e-3 .. 1e3 and moved, per seed
 RICH = int(os.environ.get("RICH", "0"))  # RICH=1: smooth normals, mirrors, Phong objects, more emitters, 1 280-triangle balls; RICH=2: random image shape, field of view, depth cap, first sample and seed too
 
 
@@ -76,7 +77,8 @@ def build(rng):
     for oi, (pv, pf, ob) in enumerate(parts):
         verts.append(pv); tris.append(pf + off); tri_obj.append(np.full(len(pf), oi, np.int32)); objects.append(ob); off += len(pv)
         vns.append(meshgen.vertex_normals(np.asarray(pv, np.float64), np.asarray(pf, np.int64))[pf].reshape(len(pf), 9))
-    return ra.HostScene.from_arrays(np.concatenate(verts).astype(np.float32), np.concatenate(tris).astype(np.uint32),
+    V = np.concatenate(verts) * SCALE[0] + np.asarray(SCALE[1])
+    return ra.HostScene.from_arrays(V.astype(np.float32), np.concatenate(tris).astype(np.uint32),
                                     np.concatenate(tri_obj), np.array(objects, ra.OBJECT_DTYPE),
                                     np.concatenate(vns).astype(np.float32)), [int(o["type"]) for o in objects]
 
@@ -86,6 +88,10 @@ spp = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 worst = 0.0
 for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
     rng = np.random.default_rng(seed)
+    if os.environ.get("SCALED"):
+        r2 = np.random.default_rng(seed + 10 ** 6)
+        SCALE[0] = float(10 ** r2.uniform(-3, 3))
+        SCALE[1] = tuple((r2.uniform(-1, 1, 3) * SCALE[0] * 10 ** r2.uniform(-1, 1.3)).tolist()) if r2.random() < 0.5 else (0.0, 0.0, 0.0)
     scene, kinds = build(rng)
     S = orc.OracleScene(scene.raw())
     dev.upload(scene.describe())
@@ -96,8 +102,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
         pos = tuple((w * 3.2).tolist())
     kw = {}
     if RICH >= 2:  # any image shape and field of view, any depth cap, any first sample, any seed
-        cam = ra.make_camera(int(rng.integers(8, 96)), int(rng.integers(8, 96)), int(rng.integers(15, 121)), position=pos,
-                             focus=tuple(rng.uniform(-0.3, 0.3, 3).tolist()), up=tuple(rng.normal(size=3).tolist()))
+        cam = ra.make_camera(int(rng.integers(8, 96)), int(rng.integers(8, 96)), int(rng.integers(15, 121)), position=tuple((np.asarray(pos) * SCALE[0] + np.asarray(SCALE[1])).tolist()),
+                             focus=tuple((rng.uniform(-0.3, 0.3, 3) * SCALE[0] + np.asarray(SCALE[1])).tolist()), up=tuple(rng.normal(size=3).tolist()))
         kw = dict(max_depth=int(rng.integers(1, 21)), spp_begin=int(rng.integers(0, 100)))
         sd = int(rng.integers(1, 10000))
     else:
@@ -118,5 +124,13 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
         print("seed %d kinds %s tris %d cam %s %s: same-seed rmse %.3g noise %.3g ratio %.3g | identical pixels %.3f | nan gpu %d cpu %d | rays gpu %d cpu %d | mean %.5f vs %.5f" % (
             seed, "".join(str(k) for k in kinds), scene.n_tris, "in " if max(abs(p) for p in pos) <= 1.0 else "out", integ, same, noise, ratio,
             (g == c).all(-1).mean(), int(np.isnan(g).sum()), int(np.isnan(c).sum()), int(st.n_rays), nr, float(np.nanmean(g / spp)), float(np.nanmean(c / spp))), flush=True)
+    if os.environ.get("DEPTHSCAN"):  # the path tracer at rising depth caps: where do the two sides part?
+        print("   scale %.4g offset %s camera %s" % (SCALE[0], SCALE[1], [round(float(x), 5) for x in cam.position[:]]))
+        for k, ob in enumerate(scene.raw()["objects"]):
+            print("   object %d type %d ior %g tris %d ss %s sa %s g %g" % (k, ob["type"], ob["ior"], ob["tri_count"], ob["sigma_s"], ob["sigma_a"], ob["g"]))
+        for depth in range(1, min(kw.get("max_depth", 20), 12) + 1):
+            k2 = dict(kw); k2["max_depth"] = depth
+            g, st = dev.render_pt(cam, spp, seed=sd, **k2); c, nr = S.render(cam, spp, seed=sd, threads=16, **k2)
+            print("   depth cap %2d: rays gpu %d cpu %d, identical pixels %.3f, mean %.5f vs %.5f" % (depth, int(st.n_rays), nr, (g == c).all(-1).mean(), g.mean() / spp, c.mean() / spp), flush=True)
     S.close(); scene.close()
 print("worst same-seed / noise ratio %.3g" % worst)
