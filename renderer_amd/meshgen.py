@@ -238,3 +238,71 @@ def random_rays(n, seed, n_objects, inside_obj=-1):
     contact = rng.integers(-1, n_objects, n)
     inside = np.where(rng.random(n) < 0.8, -1, inside_obj)
     return o, d.astype(np.float32), ra.pack_ids(contact, inside)
+
+
+# ---- random scenes with media (scripts/fuzz_media.py, tests/test_gpu_fog.py) -------------------------------------
+def random_medium(rng, ior=None):
+    ob = _obj(ra.OBJ_VPM, has_vn=0, ior=float(ior if ior is not None else (1.0 if rng.random() < 0.5 else rng.uniform(1.1, 1.5))))
+    ob["sigma_s"] = 10.0 ** rng.uniform(-1.5, 0.8, 3) if rng.random() < 0.8 else (0, 0, 0)
+    ob["sigma_a"] = 10.0 ** rng.uniform(-2.5, 0.0, 3)
+    ob["g"] = float(rng.choice([0.0, rng.uniform(-0.8, 0.9)]))
+    ob["volumetric"] = 1
+    return ob
+
+
+def random_media_scene(rng, rich=0, extreme=False, scale=1.0, offset=(0.0, 0.0, 0.0)):
+    """scripts/fuzz_media.py's scene: an emissive quad, optionally an outer fog cube or a floor, and 1 .. 5 closed objects
+    (cubes, displaced icospheres) that are media, glass, mirrors, glossy / Phong / diffuse objects or emitters, at random
+    places, overlapping or nested as they fall. Returns (HostScene, [object types])."""
+    RICH = rich
+    parts = []
+    lz = float(rng.uniform(-1.2, -0.6))
+    lv, lf, _ = _quad((-0.3, -0.3, lz), (0.3, -0.3, lz), (0.3, 0.3, lz), (-0.3, 0.3, lz), (0, 0, 1))
+    parts.append((lv, lf, _obj(ra.OBJ_EMISSIVE, (40, 40, 40), has_vn=0)))
+    outer = rng.random()
+    if outer < 0.5:
+        bv, bf = _box(1.5)
+        parts.append((bv, bf, random_medium(rng)))
+    elif outer < 0.8:
+        fv, ff, _ = _quad((-1.4, -0.9, -1.4), (1.4, -0.9, -1.4), (1.4, -0.9, 1.4), (-1.4, -0.9, 1.4), (0, 1, 0))
+        parts.append((fv, ff, _obj(ra.OBJ_DIFFUSE, (0.7, 0.6, 0.5), has_vn=0)))
+    for k in range(int(rng.integers(1, 6))):
+        c = rng.uniform(-0.8, 0.8, 3)
+        smooth = 0
+        if rng.random() < 0.5:
+            v, f = _box(float(rng.uniform(0.15, 0.7)), tuple(c))
+        else:
+            v, f = displaced_sphere(int(rng.integers(1, 3 + RICH)), int(rng.integers(0, 1000)), float(rng.uniform(0.15, 0.6)), c,
+                                            amp=float(rng.choice([0.0, 0.12])))
+            smooth = int(rng.integers(0, 2)) if RICH else 0  # interpolated vertex normals (also on a medium's boundary)
+        u = rng.random()
+        if u < 0.5:
+            ob = random_medium(rng)
+        elif u < 0.7:
+            ob = _obj(ra.OBJ_REFRACTIVE, (1, 1, 1), ior=float(rng.uniform(1.2, 1.7)) if not RICH or rng.random() < 0.7 else -1.0)
+        elif u < 0.85:
+            ob = _obj(ra.OBJ_GLOSSY if not RICH or rng.random() < 0.6 else ra.OBJ_PHONG, tuple(rng.uniform(0.5, 0.9, 3)),
+                              coeff=float(rng.uniform(3, 60)), color2=tuple(rng.uniform(0.1, 0.5, 3)))
+        elif RICH and u < 0.9:
+            ob = _obj(ra.OBJ_EMISSIVE, tuple(rng.uniform(2, 10, 3)))
+        else:
+            ob = _obj(ra.OBJ_DIFFUSE, tuple(rng.uniform(0.3, 0.9, 3)))
+        ob["has_vn"] = smooth
+        if extreme and rng.random() < 0.7:  # parameters at and beyond the edges of what makes sense
+            pick = lambda vals: float(vals[int(rng.integers(0, len(vals)))])
+            which = int(rng.integers(0, 6))
+            if which == 0: ob["ior"] = pick([0.0, 1e-3, 1.0, 50.0, 1e6] if int(ob["type"]) != ra.OBJ_REFRACTIVE else [0.0, 1e-3, 1.0, 50.0, 1e6, -1.0])
+            elif which == 1: ob["g"] = pick([-1.0, 1.0, 0.999, -0.999, 1e-6, 2.0])
+            elif which == 2: ob["sigma_s"] = (pick([0.0, 1e-8, 1e4]),) * 3; ob["sigma_a"] = (pick([0.0, 1e-8, 1e4]),) * 3
+            elif which == 3: ob["coeff"] = pick([0.0, -1.0, -0.5, 1e4, 1e-3])
+            elif which == 4: ob["color"] = (pick([0.0, 1.0, 2.0, -0.5, 1e-4]), pick([0.0, 1.0, 2.0]), pick([0.0, 1.0, 1e3]))
+            else: ob["decay"] = (pick([0.0, 1.0, 2.0, 0.5]),) * 3
+        parts.append((v, f, ob))
+    verts, tris, tri_obj, objects, vns, off = [], [], [], [], [], 0
+    for oi, (pv, pf, ob) in enumerate(parts):
+        verts.append(pv); tris.append(pf + off); tri_obj.append(np.full(len(pf), oi, np.int32)); objects.append(ob); off += len(pv)
+        vns.append(vertex_normals(np.asarray(pv, np.float64), np.asarray(pf, np.int64))[pf].reshape(len(pf), 9))
+    V = np.concatenate(verts) * scale + np.asarray(offset)
+    return ra.HostScene.from_arrays(V.astype(np.float32), np.concatenate(tris).astype(np.uint32),
+                                    np.concatenate(tri_obj), np.array(objects, ra.OBJECT_DTYPE),
+                                    np.concatenate(vns).astype(np.float32)), [int(o["type"]) for o in objects]

@@ -20,67 +20,8 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((np.clip(a, 0, 1) - np.clip(b, 0, 1)) ** 2)))
 
 
-def medium(rng, ior=None):
-    ob = meshgen._obj(ra.OBJ_VPM, has_vn=0, ior=float(ior if ior is not None else (1.0 if rng.random() < 0.5 else rng.uniform(1.1, 1.5))))
-    ob["sigma_s"] = 10.0 ** rng.uniform(-1.5, 0.8, 3) if rng.random() < 0.8 else (0, 0, 0)
-    ob["sigma_a"] = 10.0 ** rng.uniform(-2.5, 0.0, 3)
-    ob["g"] = float(rng.choice([0.0, rng.uniform(-0.8, 0.9)]))
-    ob["volumetric"] = 1
-    return ob
-
-
 def build(rng):
-    parts = []
-    lz = float(rng.uniform(-1.2, -0.6))
-    lv, lf, _ = meshgen._quad((-0.3, -0.3, lz), (0.3, -0.3, lz), (0.3, 0.3, lz), (-0.3, 0.3, lz), (0, 0, 1))
-    parts.append((lv, lf, meshgen._obj(ra.OBJ_EMISSIVE, (40, 40, 40), has_vn=0)))
-    outer = rng.random()
-    if outer < 0.5:
-        bv, bf = meshgen._box(1.5)
-        parts.append((bv, bf, medium(rng)))
-    elif outer < 0.8:
-        fv, ff, _ = meshgen._quad((-1.4, -0.9, -1.4), (1.4, -0.9, -1.4), (1.4, -0.9, 1.4), (-1.4, -0.9, 1.4), (0, 1, 0))
-        parts.append((fv, ff, meshgen._obj(ra.OBJ_DIFFUSE, (0.7, 0.6, 0.5), has_vn=0)))
-    for k in range(int(rng.integers(1, 6))):
-        c = rng.uniform(-0.8, 0.8, 3)
-        smooth = 0
-        if rng.random() < 0.5:
-            v, f = meshgen._box(float(rng.uniform(0.15, 0.7)), tuple(c))
-        else:
-            v, f = meshgen.displaced_sphere(int(rng.integers(1, 3 + RICH)), int(rng.integers(0, 1000)), float(rng.uniform(0.15, 0.6)), c,
-                                            amp=float(rng.choice([0.0, 0.12])))
-            smooth = int(rng.integers(0, 2)) if RICH else 0  # interpolated vertex normals (also on a medium's boundary)
-        u = rng.random()
-        if u < 0.5:
-            ob = medium(rng)
-        elif u < 0.7:
-            ob = meshgen._obj(ra.OBJ_REFRACTIVE, (1, 1, 1), ior=float(rng.uniform(1.2, 1.7)) if not RICH or rng.random() < 0.7 else -1.0)
-        elif u < 0.85:
-            ob = meshgen._obj(ra.OBJ_GLOSSY if not RICH or rng.random() < 0.6 else ra.OBJ_PHONG, tuple(rng.uniform(0.5, 0.9, 3)),
-                              coeff=float(rng.uniform(3, 60)), color2=tuple(rng.uniform(0.1, 0.5, 3)))
-        elif RICH and u < 0.9:
-            ob = meshgen._obj(ra.OBJ_EMISSIVE, tuple(rng.uniform(2, 10, 3)))
-        else:
-            ob = meshgen._obj(ra.OBJ_DIFFUSE, tuple(rng.uniform(0.3, 0.9, 3)))
-        ob["has_vn"] = smooth
-        if os.environ.get("EXTREME") and rng.random() < 0.7:  # parameters at and beyond the edges of what makes sense
-            pick = lambda vals: float(vals[int(rng.integers(0, len(vals)))])
-            which = int(rng.integers(0, 6))
-            if which == 0: ob["ior"] = pick([0.0, 1e-3, 1.0, 50.0, 1e6] if int(ob["type"]) != ra.OBJ_REFRACTIVE else [0.0, 1e-3, 1.0, 50.0, 1e6, -1.0])
-            elif which == 1: ob["g"] = pick([-1.0, 1.0, 0.999, -0.999, 1e-6, 2.0])
-            elif which == 2: ob["sigma_s"] = (pick([0.0, 1e-8, 1e4]),) * 3; ob["sigma_a"] = (pick([0.0, 1e-8, 1e4]),) * 3
-            elif which == 3: ob["coeff"] = pick([0.0, -1.0, -0.5, 1e4, 1e-3])
-            elif which == 4: ob["color"] = (pick([0.0, 1.0, 2.0, -0.5, 1e-4]), pick([0.0, 1.0, 2.0]), pick([0.0, 1.0, 1e3]))
-            else: ob["decay"] = (pick([0.0, 1.0, 2.0, 0.5]),) * 3
-        parts.append((v, f, ob))
-    verts, tris, tri_obj, objects, vns, off = [], [], [], [], [], 0
-    for oi, (pv, pf, ob) in enumerate(parts):
-        verts.append(pv); tris.append(pf + off); tri_obj.append(np.full(len(pf), oi, np.int32)); objects.append(ob); off += len(pv)
-        vns.append(meshgen.vertex_normals(np.asarray(pv, np.float64), np.asarray(pf, np.int64))[pf].reshape(len(pf), 9))
-    V = np.concatenate(verts) * SCALE[0] + np.asarray(SCALE[1])
-    return ra.HostScene.from_arrays(V.astype(np.float32), np.concatenate(tris).astype(np.uint32),
-                                    np.concatenate(tri_obj), np.array(objects, ra.OBJECT_DTYPE),
-                                    np.concatenate(vns).astype(np.float32)), [int(o["type"]) for o in objects]
+    return meshgen.random_media_scene(rng, rich=RICH, extreme=bool(os.environ.get("EXTREME")), scale=SCALE[0], offset=SCALE[1])
 
 
 dev = ra.Device(device=0)
