@@ -11,27 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import renderer_amd as ra, orc
 import test_gpu_fuzz as F
 
-def axis_rays(rng, v, o, d, scale):
-    """AXIS=1: half of the rays replaced by rays that barely move along one or two axes (direction components of
-    1e-8 .. 1e-2) and pass through a corner, an edge midpoint or an interior point of a triangle"""
-    n = o.shape[1]
-    sel = np.nonzero(rng.random(n) < 0.5)[0]
-    m = len(sel)
-    k = rng.integers(0, len(v), m)
-    w = rng.dirichlet((1, 1, 1), m)
-    pick = rng.integers(0, 4, m)
-    w[pick == 0] = (1, 0, 0)
-    w[pick == 1] = (0.5, 0.5, 0)
-    target = (v[k].astype(np.float64) * w[:, :, None]).sum(1)
-    dd = rng.normal(size=(m, 3))
-    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
-    small = rng.random((m, 3)) < 0.45
-    small[small.all(1), 0] = False  # (at most two small components)
-    dd = np.where(small, dd * 10.0 ** rng.uniform(-8, -2, (m, 3)), dd)
-    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
-    dist = rng.uniform(0.05, 3.0, (m, 1)) * scale
-    o[:, sel] = (target - dd * dist).T.astype(np.float32)
-    d[:, sel] = dd.T.astype(np.float32)
+axis_rays = F._axis_rays  # (the generator lives with the tests that use it too)
 
 
 first, count = int(sys.argv[1]), int(sys.argv[2])

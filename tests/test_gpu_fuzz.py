@@ -63,6 +63,29 @@ def _rays(rng, v, n, n_obj, ra, scale=1.0, offset=(0.0, 0.0, 0.0), tri_obj=None)
             ra.pack_ids(contact, inside), k2.astype(np.int32))
 
 
+def _axis_rays(rng, v, o, d, scale):
+    """scripts/fuzz_campaign.py AXIS=1: half of the rays replaced by rays that barely move along one or two axes (direction components of
+    1e-8 .. 1e-2) and pass through a corner, an edge midpoint or an interior point of a triangle"""
+    n = o.shape[1]
+    sel = np.nonzero(rng.random(n) < 0.5)[0]
+    m = len(sel)
+    k = rng.integers(0, len(v), m)
+    w = rng.dirichlet((1, 1, 1), m)
+    pick = rng.integers(0, 4, m)
+    w[pick == 0] = (1, 0, 0)
+    w[pick == 1] = (0.5, 0.5, 0)
+    target = (v[k].astype(np.float64) * w[:, :, None]).sum(1)
+    dd = rng.normal(size=(m, 3))
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    small = rng.random((m, 3)) < 0.45
+    small[small.all(1), 0] = False  # (at most two small components)
+    dd = np.where(small, dd * 10.0 ** rng.uniform(-8, -2, (m, 3)), dd)
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    dist = rng.uniform(0.05, 3.0, (m, 1)) * scale
+    o[:, sel] = (target - dd * dist).T.astype(np.float32)
+    d[:, sel] = dd.T.astype(np.float32)
+
+
 @pytest.mark.parametrize("seed,n_tri", [(1, 60), (2, 400), (3, 2500), (4, 12000), (5, 1000), (6, 5000)])
 def test_triangle_soup_against_oracle(gpu, ra, orc, seed, n_tri):
     rng = np.random.default_rng(1000 + seed)
@@ -341,4 +364,40 @@ def test_special_value_scene(gpu, ra, orc, value):
         assert int(st.n_rays) > 0
     S.close()
     s2.close()
+    scene.close()
+
+
+@pytest.mark.parametrize("seed,level", [(61, 2), (62, 4)])
+def test_mesh_scene_with_near_axis_rays(gpu, ra, orc, seed, level):
+    """A slice of scripts/fuzz_campaign.py MESH=1 AXIS=1 inside the suite: closed meshes inside Cornell walls (shared
+    edges and corners: exact ties), half of the rays barely moving along one or two axes and passing through corners, edge
+    midpoints and interiors: ids and t bit for bit in the three modes; visibility flags equal but for grazing hits."""
+    rng = np.random.default_rng(seed)
+    m = meshgen.cornell_with_meshes(level, seed, smooth=bool(seed & 1))
+    scene = ra.HostScene.from_arrays(m["verts"], m["tris"], m["tri_obj"], m["objects"], m["tri_vn"])
+    v = m["verts"][m["tris"].astype(np.int64)]
+    n_obj = len(m["objects"])
+    S = orc.OracleScene(scene.raw())
+    gpu.upload(scene.describe())
+    n = 100000
+    o, d, aux, last = _rays(rng, v, n, n_obj, ra, tri_obj=m["tri_obj"])
+    _axis_rays(rng, v, o, d, 1.0)
+    for mode, a in ((0, None), (1, last), (2, aux)):
+        tg, ig = gpu.intersect(o, d, a, mode)
+        tc, ic = S.intersect(o, d, a, mode, threads=16)
+        assert np.array_equal(ig, ic) and np.array_equal(tg, tc, equal_nan=True), (mode, int((ig != ic).sum()))
+    tc, ic = S.intersect(o, d, aux, 2, threads=16)
+    lim = np.where(ic >= 0, tc, 1.0).astype(np.float32)
+    lim = (lim * rng.choice(np.array([0.5, 1.0 - 1e-6, 1.0, 1.0 + 1e-6, 1.0 + 1e-4, 2.0, 100.0], np.float32), n)).astype(np.float32)
+    for mode, a in ((2, aux), (0, None), (1, last)):
+        vg = gpu.visibility(o, d, a, lim, mode)
+        vc = S.visibility(o, d, a, lim, mode, threads=16)
+        diff = np.nonzero(vg != vc)[0]
+        assert len(diff) <= 1e-4 * n
+        tq, iq = S.intersect(o[:, diff], d[:, diff], None if a is None else a[diff], mode, threads=4)
+        for j, q in enumerate(diff):  # (tolerated: an occluder met at a grazing angle, its reference t just before the limit)
+            w = v[iq[j]].astype(np.float64)
+            nn = np.cross(w[1] - w[0], w[2] - w[1])
+            assert iq[j] >= 0 and abs(float(nn @ d[:, q])) <= 1e-3 * np.linalg.norm(nn), (mode, q)
+    S.close()
     scene.close()
